@@ -1,0 +1,178 @@
+"""Seeded synthetic candidate sites of the reference's input shape.
+
+There is no network for HG002 data or the published checkpoint, so benchmarks and parity tests
+run on pileups drawn by this generator.  The convolution cost is data independent; the generator
+is realistic only as far as needed to exercise the allele-match predicate, empty rows, read
+start/end tokens, gap columns and inserts:
+
+* ``ref`` tokens uniform in {A,T,G,C} with 1 % gap/N (token 5);
+* coverage ``n ~ clip(N(0.78 R, 0.19 R), 1, R)`` non-empty rows (50 +- 12 at R = 64), the rest all-pad;
+* a non-empty row covers a contiguous span of ~0.75 L columns placed uniformly, token 6 / 7 at the
+  span ends, 0 outside; tokens follow ``ref`` with 1 % substitutions and 0.5 % gaps, ``noinsert``
+  (8) where ``ref`` is a gap;
+* one allele per site -- 80 % SNP, 10 % insert (<= 5 bases), 10 % delete (<= 5 bases) -- carried by a
+  fraction AF in {0.1, 0.5, 1.0} of the rows that cover the centre;
+* ``q ~ U{2..41}`` on covered columns, strand in {1, 2} per row;
+* allele masks built by ``dl4vc_amd.alleles`` (row A3).
+
+Layout is the HDF5-native one: ``reads/qual/strand[site][read][pos]`` uint8, ``ref/ref_mask/var_mask
+[site][pos]`` uint8.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from . import vocab as V
+from .alleles import allele_mask_vectors, CENTER
+
+_BASES = "ATGC"        # token t (1..4) -> character _BASES[t-1]
+
+
+@dataclass
+class SiteBatch:
+    reads: np.ndarray       # (B,R,L) u8
+    qual: np.ndarray        # (B,R,L) u8
+    strand: np.ndarray      # (B,R,L) u8
+    ref: np.ndarray         # (B,L) u8
+    ref_mask: np.ndarray    # (B,L) u8
+    var_mask: np.ndarray    # (B,L) u8
+    vcfrec: List[str]
+    num_reads: np.ndarray   # (B,) i32  rows that carry a read
+
+    def __len__(self):
+        return self.reads.shape[0]
+
+    def slice(self, lo, hi) -> "SiteBatch":
+        return SiteBatch(self.reads[lo:hi], self.qual[lo:hi], self.strand[lo:hi], self.ref[lo:hi],
+                         self.ref_mask[lo:hi], self.var_mask[lo:hi], self.vcfrec[lo:hi], self.num_reads[lo:hi])
+
+    def arrays(self):
+        return self.reads, self.qual, self.strand, self.ref, self.ref_mask, self.var_mask
+
+
+def make_sites(n_sites: int, reads: int = 64, length: int = 201, seed: int = 0,
+               chrom: str = "chr20", first_pos: int = 100000) -> SiteBatch:
+    if length != 201:
+        return _make_sites_generic(n_sites, reads, length, seed, chrom, first_pos)
+    rng = np.random.default_rng(seed)
+    B, R, L = n_sites, reads, length
+    rd = np.zeros((B, R, L), np.uint8)
+    ql = np.zeros((B, R, L), np.uint8)
+    st = np.zeros((B, R, L), np.uint8)
+    rf = np.zeros((B, L), np.uint8)
+    rmask = np.zeros((B, L), np.uint8)
+    vmask = np.zeros((B, L), np.uint8)
+    recs: List[str] = []
+    nreads = np.zeros(B, np.int32)
+    span = int(round(0.75 * L))
+    for b in range(B):
+        ref = rng.integers(1, 5, L).astype(np.uint8)
+        ref[rng.random(L) < 0.01] = V.GAP
+        ref[CENTER - 1:CENTER + 8] = np.where(ref[CENTER - 1:CENTER + 8] == V.GAP,
+                                              rng.integers(1, 5, 9), ref[CENTER - 1:CENTER + 8])
+        kind = rng.random()
+        af = (0.1, 0.5, 1.0)[rng.integers(0, 3)]
+        n = int(np.clip(round(rng.normal(0.78 * R, 0.19 * R)), 1, R))
+        nreads[b] = n
+        ref_base = int(ref[CENTER])
+        if kind < 0.8:                                   # SNP
+            alt = int(rng.choice([t for t in (1, 2, 3, 4) if t != ref_base]))
+            ref_s, alt_s = _BASES[ref_base - 1], _BASES[alt - 1]
+            ins_len = del_len = 0
+        elif kind < 0.9:                                 # insert: open gap columns after the centre
+            ins_len = int(rng.integers(1, 6))
+            ins = rng.integers(1, 5, ins_len)
+            ref[CENTER + 1:CENTER + 1 + ins_len] = V.GAP
+            ref_s = _BASES[ref_base - 1]
+            alt_s = ref_s + "".join(_BASES[t - 1] for t in ins)
+            del_len = 0
+        else:                                            # delete
+            del_len = int(rng.integers(1, 6))
+            ref_s = "".join(_BASES[t - 1] for t in ref[CENTER:CENTER + 1 + del_len])
+            alt_s = _BASES[ref_base - 1]
+            ins_len = 0
+        for r in range(n):
+            lo = int(rng.integers(0, L - span + 1))
+            hi = lo + span                               # covered columns [lo, hi)
+            row = ref[lo:hi].copy()
+            sub = rng.random(span) < 0.01
+            row[sub] = rng.integers(1, 5, int(sub.sum()))
+            row[rng.random(span) < 0.005] = V.GAP
+            row[ref[lo:hi] == V.GAP] = V.NOINSERT
+            covers = lo < CENTER - 1 and hi > CENTER + 8
+            carries = covers and (rng.random() < af)
+            if covers:
+                c = CENTER - lo
+                row[c] = ref_base                          # clean centre unless the allele is carried
+                if ins_len:
+                    row[c + 1:c + 1 + ins_len] = V.NOINSERT
+                if carries:
+                    if kind < 0.8:
+                        row[c] = alt
+                    elif ins_len:
+                        row[c + 1:c + 1 + ins_len] = ins
+                    else:
+                        row[c + 1:c + 1 + del_len] = V.GAP
+            row[0], row[-1] = V.START, V.END
+            rd[b, r, lo:hi] = row
+            ql[b, r, lo:hi] = rng.integers(2, 42, span)
+            st[b, r, lo:hi] = rng.integers(1, 3)
+        rf[b] = ref
+        rec = "\t".join((chrom, str(first_pos + 7 * b), ".", ref_s, alt_s, "50", ".",
+                         "DP=%d;AF=%.4f" % (n, af), "GT:GQ", "1:50"))
+        recs.append(rec)
+        rmask[b], vmask[b] = allele_mask_vectors(rec, ref)
+    return SiteBatch(rd, ql, st, rf, rmask, vmask, recs, nreads)
+
+
+def _make_sites_generic(n_sites, reads, length, seed, chrom, first_pos) -> SiteBatch:
+    """Windows other than 201 columns (stress shape 128 x 301): SNP-only alleles at column 100, masks
+    written directly (the reference's mask builder is hard-wired to 201 columns, dataset.py:114)."""
+    rng = np.random.default_rng(seed)
+    B, R, L = n_sites, reads, length
+    rf = rng.integers(1, 5, (B, L)).astype(np.uint8)
+    rd = np.zeros((B, R, L), np.uint8)
+    ql = np.zeros((B, R, L), np.uint8)
+    st = np.zeros((B, R, L), np.uint8)
+    rmask = np.zeros((B, L), np.uint8)
+    vmask = np.zeros((B, L), np.uint8)
+    recs, nreads = [], np.zeros(B, np.int32)
+    span = int(round(0.75 * L))
+    for b in range(B):
+        n = int(np.clip(round(rng.normal(0.78 * R, 0.19 * R)), 1, R))
+        nreads[b] = n
+        ref_base = int(rf[b, CENTER])
+        alt = int(rng.choice([t for t in (1, 2, 3, 4) if t != ref_base]))
+        af = (0.1, 0.5, 1.0)[rng.integers(0, 3)]
+        for r in range(n):
+            lo = int(rng.integers(0, L - span + 1))
+            hi = lo + span
+            row = rf[b, lo:hi].copy()
+            sub = rng.random(span) < 0.01
+            row[sub] = rng.integers(1, 5, int(sub.sum()))
+            if lo < CENTER < hi - 1 and lo != CENTER:
+                row[CENTER - lo] = alt if rng.random() < af else ref_base
+            row[0], row[-1] = V.START, V.END
+            rd[b, r, lo:hi] = row
+            ql[b, r, lo:hi] = rng.integers(2, 42, span)
+            st[b, r, lo:hi] = rng.integers(1, 3)
+        rmask[b, CENTER] = ref_base
+        vmask[b, CENTER] = alt
+        recs.append("\t".join((chrom, str(first_pos + 7 * b), ".", _BASES[ref_base - 1], _BASES[alt - 1],
+                               "50", ".", "DP=%d;AF=%.4f" % (n, af), "GT:GQ", "1:50")))
+    return SiteBatch(rd, ql, st, rf, rmask, vmask, recs, nreads)
+
+
+def tile_sites(batch: SiteBatch, n_sites: int) -> SiteBatch:
+    """Repeat a generated batch up to ``n_sites`` (bench sizes: generating 65 536 distinct sites in
+    Python would take minutes; the forward's cost is data independent)."""
+    reps = -(-n_sites // len(batch))
+
+    def t(a):
+        return np.concatenate([a] * reps, axis=0)[:n_sites]
+
+    return SiteBatch(t(batch.reads), t(batch.qual), t(batch.strand), t(batch.ref), t(batch.ref_mask),
+                     t(batch.var_mask), (batch.vcfrec * reps)[:n_sites], t(batch.num_reads))

@@ -1,0 +1,464 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); nothing of the reference's source
+travels: the fixtures hold inputs, seeded weights and the reference's outputs.
+
+The reference cannot be imported as-is here; each obstacle is an ordinary Python error with a
+one-line shim:
+  * ``import h5py`` / ``import pysam`` at module top  -> stub modules (h5py stub serves a numpy
+    structured array so that dl4vc/dataset.py's generator can be driven without libhdf5)
+  * hard-coded ``.cuda()`` inside forward             -> ``torch.Tensor.cuda`` = identity
+  * ``np.string_`` (removed in numpy 2)               -> alias of ``np.bytes_``
+
+Usage:  python oracle/gen_golden.py            (rewrites tests/golden/*)
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle.dan_oracle import OracleSpec, random_state_dict, dan_forward_oracle   # noqa: E402
+from dl4vc_amd import synth                                                       # noqa: E402
+from dl4vc_amd.hdf5_schema import record_dtype                                    # noqa: E402
+
+
+# --------------------------------------------------------------------------------------------
+# reference import with shims
+# --------------------------------------------------------------------------------------------
+class _FakeH5File:
+    """Stands in for h5py.File: ``path`` is an .npy file holding the structured record array."""
+    def __init__(self, path, mode="r"):
+        self._data = np.load(path, allow_pickle=False)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def __getitem__(self, k):
+        assert k == "data"
+        return self._data
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present at %s" % REF)
+    h5 = types.ModuleType("h5py")
+    h5.File = _FakeH5File
+    sys.modules.setdefault("h5py", h5)
+    sys.modules.setdefault("pysam", types.ModuleType("pysam"))
+    if not hasattr(np, "string_"):
+        np.string_ = np.bytes_
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "tools"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        import dl4vc.model as m
+        import dl4vc.dataset as d
+        import dl4vc.utils as u
+    return m, d, u
+
+
+def ref_args(**over):
+    a = types.SimpleNamespace(use_transformer=False, transformer_encoder_heads=4, num_transformer_layers=4,
+                              transformer_feedforward_dim=64, final_transformer_dims=64,
+                              transformer_residual=False, transformer_encoder_dropout=0.1,
+                              model_use_q_scores=True, model_use_strands=True, aux_keep_candidate_af=True)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def build_reference_model(m, spec: OracleSpec, dropout=0.1):
+    # dl4vc/model.py builds its pooling layers from the module constant MAX_READS (100); fine for R <= 100.
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = m.Basic2DNet(target_size=3, layer_sizes=list(spec.fc_sizes), hidden_dropout=dropout,
+                           init_conv_channels=spec.c_init, final_conv_channels=spec.c_final,
+                           use_q_scores=spec.use_q, use_strands=spec.use_strand,
+                           use_reads_ref_var_mask=spec.use_mask,
+                           single_read_len=spec.length, num_single_reads=spec.reads,
+                           bottleneck_channels=spec.bottleneck, bottleneck_linear_outputs=spec.bottleneck,
+                           append_bottleneck_highway_reads=spec.bottleneck > 0, concat_hw_reads=True,
+                           total_conv_layers=spec.layers, residual_layer_start=spec.residual_start,
+                           conv_1d_pool_layers=list(spec.pool_layers), use_batchnorm=spec.use_bn,
+                           pool_combine_dimension=0, final_layer_dilation=spec.dil_final,
+                           middle_layer_dilation=spec.dil_mid, args=ref_args())
+    return net.eval()
+
+
+def run_reference(m, spec: OracleSpec, sd_np, batch: synth.SiteBatch, dropout=0.1, taps=True):
+    net = build_reference_model(m, spec, dropout)
+    sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    for k, v in net.state_dict().items():               # BN bookkeeping the reference carries, not a weight
+        if k.endswith("num_batches_tracked"):
+            sd_t[k] = v
+    net.load_state_dict(sd_t, strict=True)              # strict: our key names/shapes ARE the reference's
+    cap = {}
+    hooks = []
+    if taps:
+        if spec.bottleneck > 0:
+            for i, mod in enumerate(net.conv1D_bottleneck_layers):
+                hooks.append(mod.register_forward_pre_hook(
+                    lambda _m, inp, i=i: cap.__setitem__("conv%d" % (i + 1), inp[0].detach().numpy().copy())))
+            for i, mod in enumerate(net.conv1D_compression_layers):
+                hooks.append(mod.register_forward_hook(
+                    lambda _m, inp, out, i=i: cap.__setitem__(
+                        "hw%d" % (i + 1), out.detach().squeeze(3).reshape(out.shape[0], -1).numpy().copy())))
+        hooks.append(net.conv2hidden.register_forward_pre_hook(
+            lambda _m, inp: cap.__setitem__("feature", inp[0].detach().numpy().copy())))
+        hooks.append(net.conv2hidden.register_forward_hook(
+            lambda _m, inp, out: cap.__setitem__("hidden", out.detach().numpy().copy())))
+
+    def pm(a):      # our [B][R][L] -> the reference's (B, L, R) int64  (dataset.py:521, trainer.py:520-528)
+        return torch.from_numpy(np.ascontiguousarray(np.transpose(a, (0, 2, 1)))).long()
+
+    B = len(batch)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        outs = net(pm(batch.reads), torch.from_numpy(batch.ref).long(), q_scores=pm(batch.qual),
+                   strands=pm(batch.strand), binary_trust_vector=torch.ones(B, 1),
+                   af_scores=torch.zeros(B, 1), ref_bases=torch.zeros(B, 51).long(),
+                   var_bases=torch.zeros(B, 51).long(),
+                   ref_masks=torch.from_numpy(batch.ref_mask).long(),
+                   var_masks=torch.from_numpy(batch.var_mask).long())
+    for h in hooks:
+        h.remove()
+    xbin, xvt, xaf, xcov, xvb, xvr = [o.numpy() for o in outs[:6]]
+    res = dict(bin_logits=xbin, vt_logits=xvt, af=xaf, cov=xcov, vb=xvb, vr=xvr)
+    # trainer.py:620-623
+    res["bp"] = (1.0 - torch.softmax(outs[0], dim=1)[:, 0]).numpy()
+    res["vt_prob"] = torch.softmax(outs[1], dim=1).numpy()
+    res.update(cap)
+    return res
+
+
+# --------------------------------------------------------------------------------------------
+# hand-made edge sites appended to the generated ones
+# --------------------------------------------------------------------------------------------
+def edge_sites(R: int) -> synth.SiteBatch:
+    """SNP / delete / insert / delete-with-gap masks, an all-pad pileup, a site where no read agrees,
+    and a blacklisted site (all-zero masks)."""
+    base = synth.make_sites(7, reads=R, seed=1234)
+    rd, ql, st, rf = base.reads.copy(), base.qual.copy(), base.strand.copy(), base.ref.copy()
+    rmask = np.zeros_like(base.ref_mask)
+    vmask = np.zeros_like(base.var_mask)
+    recs = []
+    from dl4vc_amd.alleles import allele_mask_vectors
+    B = "ATGC"
+
+    def rec(ref_s, alt_s):
+        return "\t".join(("chr1", "1000", ".", ref_s, alt_s, "50", ".", "DP=8;AF=0.5", "GT:GQ", "1:50"))
+
+    def clean(b):       # every row = the reference over its whole window (so masks decide the channels)
+        for r in range(R):
+            rd[b, r] = np.where(rf[b] == 5, 8, rf[b])
+            ql[b, r] = 30
+            st[b, r] = 1 + (r & 1)
+
+    for b in range(7):
+        rf[b, 95:112] = np.array([1, 2, 3, 4, 1, 1, 2, 3, 4, 2, 3, 1, 4, 2, 1, 3, 4], np.uint8)
+        clean(b)
+    # 0: SNP A->G, half the reads carry it
+    recs.append(rec("A", "G")); rd[0, ::2, 100] = 3
+    # 1: delete ATG->A (ref[100..102] = A T G)
+    rf[1, 100:103] = (1, 2, 3); clean(1); recs.append(rec("ATG", "A")); rd[1, :3, 101:103] = 5
+    # 2: insert A->ATT: gap columns 101,102 in the reference
+    rf[2, 100] = 1; rf[2, 101:103] = 5; clean(2); recs.append(rec("A", "ATT")); rd[2, 1::3, 101:103] = 2
+    # 3: delete ATG->A with a gap column inside the span (another allele's insert): ref = A - T G
+    rf[3, 100:104] = (1, 5, 2, 3); clean(3); recs.append(rec("ATG", "A")); rd[3, :2, 102:104] = 5
+    # 4: all-pad pileup (no reads at all)
+    recs.append(rec(B[rf[4, 100] - 1], "C" if rf[4, 100] != 4 else "A")); rd[4] = 0; ql[4] = 0; st[4] = 0
+    # 5: no read agrees with ref or var (every read shows a third base at the centre)
+    rf[5, 100] = 1; clean(5); recs.append(rec("A", "G")); rd[5, :, 100] = 4
+    # 6: blacklisted: first ref base not found in the window -> zero masks
+    rf[6, 100] = 2; clean(6); recs.append(rec("A", "G"))
+    for b in range(7):
+        try:
+            rmask[b], vmask[b] = allele_mask_vectors(recs[b], rf[b])
+        except AssertionError:
+            pass
+    return synth.SiteBatch(rd, ql, st, rf, rmask, vmask, recs, np.full(7, R, np.int32))
+
+
+def concat(a: synth.SiteBatch, b: synth.SiteBatch) -> synth.SiteBatch:
+    return synth.SiteBatch(*(np.concatenate((x, y)) for x, y in zip(a.arrays(), b.arrays())),
+                           a.vcfrec + b.vcfrec, np.concatenate((a.num_reads, b.num_reads)))
+
+
+def save_case(name, spec: OracleSpec, sd, batch, ref_out, dropout_keys=True):
+    payload = {"spec_json": np.frombuffer(json.dumps(spec.__dict__, default=list).encode(), np.uint8)}
+    for k, v in sd.items():
+        payload["w:" + k] = v
+    for k, v in zip(("reads", "qual", "strand", "ref", "ref_mask", "var_mask"), batch.arrays()):
+        payload["in:" + k] = v
+    for k, v in ref_out.items():
+        payload["out:" + k] = v.astype(np.float32) if v.dtype != np.float32 else v
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **payload)
+    print("wrote %-28s %7.1f KB" % (os.path.basename(path), os.path.getsize(path) / 1024))
+
+
+def check_oracle(spec, sd, batch, ref_out, tag):
+    mine = dan_forward_oracle(sd, spec, *batch.arrays(), taps=True)
+    worst = 0.0
+    for k, v in ref_out.items():
+        d = float(np.max(np.abs(mine[k].astype(np.float64) - v.astype(np.float64)))) if v.size else 0.0
+        scale = max(1.0, float(np.max(np.abs(v)))) if v.size else 1.0
+        worst = max(worst, d / scale)
+    print("   oracle vs reference [%s]: worst rel-to-max diff %.3g" % (tag, worst))
+    assert worst < 2e-5, "oracle disagrees with the reference"
+    return worst
+
+
+# --------------------------------------------------------------------------------------------
+def gen_model_fixtures(m):
+    # G-small: all production structural flags, tiny widths
+    small = OracleSpec(reads=8, length=201, layers=7, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8))
+    sd = random_state_dict(small, seed=11)
+    batch = concat(edge_sites(8), synth.make_sites(5, reads=8, seed=5))
+    out = run_reference(m, small, sd, batch, taps=True)
+    check_oracle(small, sd, batch, out, "G-small")
+    # per-layer taps are large: keep layers 2 and 7 for the first 4 sites only (tests slice the same way)
+    keep = {k: v for k, v in out.items() if not k.startswith("conv")}
+    keep["conv2"] = out["conv2"][:4]
+    keep["conv7"] = out["conv7"][:4]
+    save_case("dan_small", small, sd, batch, keep)
+
+    # G-variants: one structural switch each, two sites each
+    tiny = dict(reads=4, length=201, c_init=8, c_final=8, bottleneck=2, fc_sizes=(8, 4))
+    variants = {
+        "nobn": OracleSpec(**tiny, use_bn=False),
+        "noqs": OracleSpec(**tiny, use_q=False, use_strand=False),
+        "nomask": OracleSpec(**tiny, use_mask=False),
+        "nores": OracleSpec(**tiny, residual_start=0),
+        "nopool": OracleSpec(**tiny, pool_layers=()),
+        "pool24": OracleSpec(**tiny, pool_layers=(2, 4)),
+        "dil1": OracleSpec(**tiny, dil_mid=1, dil_final=1),
+        "l5res2": OracleSpec(**tiny, layers=5, residual_start=2, pool_layers=(1,), dil_mid=3, dil_final=1),
+        "cfinal": OracleSpec(**{**tiny, "c_final": 16}, residual_start=3),
+        "nohw": OracleSpec(**{**tiny, "bottleneck": 0}),
+    }
+    for i, (name, spec) in enumerate(variants.items()):
+        sdv = random_state_dict(spec, seed=100 + i, dropout_keys=(name != "nobn"))
+        b = synth.make_sites(2, reads=spec.reads, seed=200 + i)
+        o = run_reference(m, spec, sdv, b, dropout=(0.0 if name == "nobn" else 0.1), taps=False)
+        check_oracle(spec, sdv, b, o, name)
+        save_case("dan_var_" + name, spec, sdv, b, o)
+
+    # G-full-hash: production shape, oracle vs reference max-abs-diff (weights regenerated from seed)
+    log = {}
+    for R in (100, 64):
+        spec = OracleSpec(reads=R)
+        sdp = random_state_dict(spec, seed=7)
+        b = synth.make_sites(2, reads=R, seed=70 + R)
+        o = run_reference(m, spec, sdp, b, taps=False)
+        mine = dan_forward_oracle(sdp, spec, *b.arrays())
+        log["R%d" % R] = {k: float(np.max(np.abs(mine[k] - o[k]))) for k in ("vt_logits", "bin_logits", "vt_prob", "bp")}
+        log["R%d" % R]["vt_prob_ref"] = o["vt_prob"].tolist()
+        print("   full shape R=%d: %s" % (R, {k: v for k, v in log["R%d" % R].items() if k != "vt_prob_ref"}))
+        assert log["R%d" % R]["vt_prob"] < 1e-5
+    with open(os.path.join(GOLD, "full_shape_oracle_vs_reference.json"), "w") as f:
+        json.dump(log, f, indent=1)
+
+
+VCF_TABLE = [
+    # (REF, ALT, window edits)   -- window edits: list of (col, token)
+    ("A", "G", []),
+    ("C", "T", [(100, 4)]),
+    ("ATG", "A", [(100, 1), (101, 2), (102, 3)]),
+    ("ATG", "A", [(100, 1), (101, 5), (102, 2), (103, 3)]),                 # gap column inside the deletion
+    ("ATGC", "A", [(100, 1), (101, 2), (102, 5), (103, 5), (104, 3), (105, 4)]),
+    ("A", "ATT", [(100, 1), (101, 5), (102, 5)]),
+    ("A", "ACGTACGTAC", [(100, 1)] + [(101 + i, 5) for i in range(9)]),
+    ("G", "GA", [(98, 3), (99, 5), (100, 5), (101, 5)]),                     # centre is a gap: rewind to col 98
+    ("A", "G", [(100, 2)]),                                                   # ref base mismatch -> assert
+    ("AT", "GC", [(100, 1), (101, 2)]),                                       # MNP -> UnboundLocalError
+    ("ATG", "AT", [(100, 1), (101, 2), (102, 3)]),                            # delete with 2-base alt -> assert
+    ("g", "a", [(100, 3)]),                                                   # lower-case g: not a SNP there
+    ("t", "c", [(100, 2)]),
+    ("N", "A", [(100, 5), (99, 5), (98, 1)]),
+    ("ATTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", "A", [(100 + i, 1 if i == 0 else 2) for i in range(61)]),
+]
+
+
+def gen_dataset_fixtures(d, u):
+    rng = np.random.default_rng(42)
+    cases = []
+    for ref_s, alt_s, edits in VCF_TABLE:
+        window = rng.integers(1, 5, 201).astype(np.uint8)
+        for col, tok in edits:
+            window[col] = tok
+        rec = "\t".join(("chr7", "5555", ".", ref_s, alt_s, "50", ".", "DP=33;AF=0.2500", "GT:GQ", "1:50"))
+        case = {"vcfrec": rec, "window": window.tolist()}
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                rm, vm = d.get_read_mask_vectors(rec, reference=window.copy())
+                case["ref_mask"], case["var_mask"], case["error"] = rm.tolist(), vm.tolist(), None
+            except Exception as e:            # noqa: BLE001
+                case["error"] = type(e).__name__
+            r51, v51 = d.simple_variant_encoding_vectors(rec)
+            case["ref_vec51"], case["var_vec51"] = r51.tolist(), v51.tolist()
+            try:
+                info = u.parse_vcf(rec)
+                case["parse"] = {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in info.items()}
+            except Exception as e:            # noqa: BLE001
+                case["parse"] = type(e).__name__
+            if isinstance(case["parse"], dict) and "var_mode" in case["parse"]:
+                reads = rng.integers(0, 10, (201, 30)).astype(np.uint8)
+                cc = d.count_variants_from_single_reads(reads, window, case["parse"]["var_mode"])
+                case["count_reads"] = reads.tolist()
+                case["count"] = [int(x) for x in cc]
+        cases.append(case)
+    # truth-column parse cases (utils.py:59-70)
+    for gt in ("GT:1/1", "GT:0/1", "GT:1|0", "GT:0|0", "GT:./."):
+        rec = "\t".join(("chr7", "5555", ".", "A", "C", "50", ".", "AF=0.5;DP=20", "GT:GQ", "1:50", gt))
+        with contextlib.redirect_stdout(io.StringIO()):
+            info = u.parse_vcf(rec)
+        cases.append({"vcfrec": rec, "parse_only": {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v)
+                                                    for k, v in info.items()}})
+    with open(os.path.join(GOLD, "alleles.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote alleles.json (%d cases)" % len(cases))
+
+    # A2: drive the reference's dataset class over a record array in the HDF5 schema
+    dt = record_dtype(200, 201)
+    sites = synth.make_sites(6, reads=100, seed=9)
+    recs = np.zeros(6, dtype=dt)
+    stored = [37, 100, 64, 150, 200, 1]
+    rng = np.random.default_rng(3)
+    for i in range(6):
+        n = stored[i]
+        recs[i]["name"] = ("chr20:%d" % (1000 + i)).encode()
+        body = rng.integers(0, 10, (200, 201)).astype(np.uint8)
+        body[n:] = 0
+        recs[i]["single_reads"] = body
+        recs[i]["q-scores"] = rng.integers(0, 42, (200, 201)).astype(np.uint8) * (body != 0)
+        recs[i]["strand"] = rng.integers(0, 3, (200, 201)).astype(np.uint8) * (body != 0)
+        recs[i]["ref_bases"] = sites.ref[i]
+        recs[i]["num_reads"] = n
+        recs[i]["label"] = 2
+        recs[i]["vcfrec"] = sites.vcfrec[i].encode()
+    npy = os.path.join(GOLD, "records_a2.npy")
+    np.save(npy, recs)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = d.ContextDatasetFromNumpy(npy, args=ref_args(), augment_single_reads=False, augment_refernce=False)
+        items = []
+        for i in range(6):
+            np.random.seed(1000 + i)          # pins the >100-read subset (dataset.py:274-281)
+            it = ds[i]
+            items.append(it)
+    out = {}
+    for i, it in enumerate(items):
+        # the reference hands out (L, R); we store our (R, L) order
+        out["reads%d" % i] = np.ascontiguousarray(it["reads"].T)
+        out["qual%d" % i] = np.ascontiguousarray(it["q-scores"].T)
+        out["strand%d" % i] = np.ascontiguousarray(it["strands"].T)
+        out["ref%d" % i] = it["ref"]
+        out["ref_mask%d" % i] = it["ref_mask"]
+        out["var_mask%d" % i] = it["var_mask"]
+    meta = [{"vcfrec": it["vcfrec"], "name": it["name"], "num_reads": int(np.asarray(it["num_reads"]).reshape(-1)[0]),
+             "blacklist": bool(it["blacklist"]), "is_snp": bool(it["is_snp"]), "seed": 1000 + i,
+             "coverage": int(it["coverage"]), "allele_freq": float(it["allele_freq"])}
+            for i, it in enumerate(items)]
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "dataset_a2.npz"), **out)
+    os.remove(npy)
+    np.savez_compressed(os.path.join(GOLD, "records_a2.npz"), records=recs.view(np.uint8).reshape(6, -1))
+    print("wrote dataset_a2.npz / records_a2.npz")
+
+
+def gen_vcf_fixtures(u):
+    import tempfile
+    rng = np.random.default_rng(8)
+    # A16: append_vcf_records %.8f formatting of fp32 scores
+    n = 12
+    bp = torch.from_numpy(rng.random(n).astype(np.float32))
+    vt = torch.softmax(torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32) * 3), dim=1)
+    bp[0], bp[1] = 0.0, 1.0
+    recs = ["\t".join(("chr20", str(100 + i), ".", "A", "G", "50", ".", "DP=30;AF=0.5", "GT:GQ", "1:50")) + "\n"
+            for i in range(n)]
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "o.vcf")
+        open(p, "w").write("##fileformat=VCFv4.2\n")
+        u.append_vcf_records(p, bp, vt, recs)
+        lines = open(p).read()
+    fx = {"bp": bp.numpy().tolist(), "vt": vt.numpy().tolist(), "records": recs, "file": lines}
+
+    # A17: format_vcf input -> output pairs
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        fv = importlib.import_module("format_vcf")
+
+    def vline(chrom, pos, ref_s, alt_s, nv, ov, hv=None):
+        hv = (1 - nv - ov) if hv is None else hv
+        return "\t".join((chrom, str(pos), "BP=%.8f;NV=%.8f;HV=%.8f;OV=%.8f" % (1 - nv, nv, hv, ov),
+                          ref_s, alt_s, "50", ".", "DP=30;AF=0.5", "GT:GQ", "1:50"))
+
+    header = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n"
+    scenarios = {
+        "thresholds": [vline("chr1", 10, "A", "G", 0.95, 0.01), vline("chr1", 20, "A", "G", 0.899999, 0.05),
+                       vline("chr1", 30, "A", "G", 0.2, 0.75), vline("chr1", 40, "A", "G", 0.2, 0.7499),
+                       vline("chr1", 50, "AT", "A", 0.85, 0.1), vline("chr1", 60, "AT", "A", 0.75, 0.85),
+                       vline("chr1", 70, "A", "AT", 0.5, 0.79), vline("chr1", 80, "ATGG", "A", 0.1, 0.9),
+                       vline("chr1", 90, "A", "ATGC", 0.81, 0.1), vline("chr2", 5, "C", "T", 0.0, 1.0)],
+        "multi_hom": [vline("chr1", 100, "A", "G", 0.05, 0.9), vline("chr1", 100, "A", "C", 0.6, 0.1),
+                      vline("chr1", 100, "A", "T", 0.7, 0.05), vline("chr1", 200, "A", "G", 0.5, 0.1)],
+        "multi_hom_strong_second": [vline("chr1", 100, "A", "G", 0.05, 0.9), vline("chr1", 100, "A", "C", 0.02, 0.1),
+                                    vline("chr1", 300, "G", "C", 0.3, 0.2)],
+        "multi_het_top2": [vline("chr3", 7, "A", "G", 0.2, 0.1), vline("chr3", 7, "A", "C", 0.1, 0.2),
+                           vline("chr3", 7, "A", "T", 0.25, 0.1), vline("chr3", 9, "A", "T", 0.25, 0.1)],
+        "multi_het_weak_second": [vline("chr3", 7, "A", "G", 0.2, 0.1), vline("chr3", 7, "A", "C", 0.5, 0.2),
+                                  vline("chr3", 7, "A", "T", 0.6, 0.1), vline("chr3", 9, "A", "T", 0.25, 0.1)],
+        "last_line_multi": [vline("chr4", 1, "A", "G", 0.5, 0.1), vline("chr4", 2, "A", "G", 0.2, 0.1),
+                            vline("chr4", 2, "A", "C", 0.1, 0.1), vline("chr4", 2, "A", "T", 0.3, 0.1)],
+        "last_line_hom": [vline("chr4", 1, "A", "G", 0.5, 0.1), vline("chr4", 2, "A", "G", 0.2, 0.1),
+                          vline("chr4", 2, "A", "C", 0.1, 0.9)],
+        "last_below": [vline("chr4", 1, "A", "G", 0.5, 0.1), vline("chr4", 2, "A", "G", 0.95, 0.1)],
+    }
+    fmt = {}
+    for name, body in scenarios.items():
+        with tempfile.TemporaryDirectory() as td:
+            pin, pout = os.path.join(td, "in.vcf"), os.path.join(td, "out.vcf")
+            open(pin, "w").write(header + "\n".join(body) + "\n")
+            a = types.SimpleNamespace(input_file=pin, output_file=pout, snp_threshold=0.1, indel_threshold=0.2,
+                                      long_indel_threshold=0.0, delete_threshold=0.0, snp_zygo_threshold=0.75,
+                                      indel_zygo_threshold=0.8, long_indel_zygo_threshold=0.5,
+                                      delete_zygo_threshold=0.5, multiallele_second_threshold=0.7,
+                                      multiallele_homozygous_second_threshold=0.9, debug=False)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                fv.filter_format_vcf(a)
+            fmt[name] = {"input": open(pin).read(), "output": open(pout).read()}
+    fx["format_vcf"] = fmt
+    with open(os.path.join(GOLD, "vcf.json"), "w") as f:
+        json.dump(fx, f)
+    print("wrote vcf.json (%d format_vcf scenarios)" % len(fmt))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    m, d, u = import_reference()
+    which = sys.argv[1:] or ["model", "dataset", "vcf"]
+    if "model" in which:
+        gen_model_fixtures(m)
+    if "dataset" in which:
+        gen_dataset_fixtures(d, u)
+    if "vcf" in which:
+        gen_vcf_fixtures(u)
+
+
+if __name__ == "__main__":
+    main()

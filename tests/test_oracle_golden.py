@@ -1,0 +1,46 @@
+"""The oracle (oracle/dan_oracle.py) against golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+
+from golden_util import load_case, model_cases, input_tuple
+from oracle.dan_oracle import dan_forward_oracle, OracleSpec, spec_from
+
+# fp32 CPU restatement vs fp32 CPU reference: identical op sequence, so the bar is roundoff
+ATOL = 2e-5
+
+
+@pytest.mark.parametrize("case", model_cases())
+def test_oracle_matches_reference_outputs(case):
+    spec, w, inp, out = load_case(case)
+    mine = dan_forward_oracle(w, spec, *input_tuple(inp), taps=True)
+    assert set(("bin_logits", "vt_logits", "af", "cov", "vb", "vr", "bp", "vt_prob")) <= set(out)
+    for k, ref in out.items():
+        got = mine[k]
+        if k in ("conv2", "conv7"):
+            got = got[:ref.shape[0]]
+        assert got.shape == ref.shape, k
+        scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
+        np.testing.assert_allclose(got, ref, rtol=0, atol=ATOL * scale, err_msg="%s:%s" % (case, k))
+
+
+def test_small_case_covers_edge_sites():
+    spec, w, inp, out = load_case("dan_small")
+    # site 4 is an all-pad pileup, site 6 is blacklisted (zero masks); both still produce finite scores
+    assert inp["reads"][4].max() == 0
+    assert inp["ref_mask"][6].max() == 0 and inp["var_mask"][6].max() == 0
+    assert np.isfinite(out["vt_prob"]).all()
+    np.testing.assert_allclose(out["vt_prob"].sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_feature_width_formula():
+    spec = OracleSpec()
+    assert spec.feature_width == 73856
+    assert spec_from({"reads": 64}).feature_width == 65792
+    assert OracleSpec(reads=128, length=301).feature_width == 105728
+
+
+def test_fp64_oracle_close_to_fp32():
+    import torch
+    spec, w, inp, out = load_case("dan_var_pool24")
+    hi = dan_forward_oracle(w, spec, *input_tuple(inp), dtype=torch.float64)
+    np.testing.assert_allclose(hi["vt_prob"], out["vt_prob"], atol=1e-5)
