@@ -1,0 +1,584 @@
+// C ABI of libdl4vc_dan.so (include/dl4vc_dan.h): handle lifecycle, checkpoint validation and
+// MFMA-order weight packing, chunked execution plan.  Host code only; kernels are in dan_kernels.hip.
+#include "../../include/dl4vc_dan.h"
+#include "dan_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace dan;
+
+namespace {
+
+struct Tensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; };
+struct KernelStat {
+    std::vector<EventPair> pending;
+    int64_t launches = 0;
+    double ms = 0.0;
+};
+
+}  // namespace
+
+struct dan_handle {
+    dan_config cfg{};
+    std::map<std::string, Tensor> tensors;
+    bool finalized = false;
+    mutable std::string err;
+    int n_segments = 0;
+    std::vector<int> seg_begin, seg_end;     // 0-based layer ranges
+    int F = 0;                               // feature width
+    int64_t F_stride = 0;                    // padded to a multiple of 16
+    int n0_stride = 0;                       // fc_sizes[0] padded to a multiple of 16 (K of the second FC)
+    int chunk = 0, max_batch = 0;
+    int tap_layer = -1;
+    int last_chunk_sites = 0;
+    int64_t last_batch = 0;
+    // device memory
+    std::vector<void*> allocs;
+    LayerDesc* d_layers = nullptr;
+    float *d_emb = nullptr, *d_pe = nullptr;
+    float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
+    float *d_wc = nullptr, *d_bc = nullptr;
+    float *d_feat = nullptr, *d_hid0 = nullptr, *d_hid1 = nullptr;
+    float *d_w0 = nullptr, *d_b0 = nullptr, *d_w1 = nullptr, *d_b1 = nullptr, *d_wh = nullptr, *d_bh = nullptr;
+    // staging for the host-pointer entry points
+    uint8_t* d_in = nullptr;
+    float* d_out = nullptr;
+    // profiling
+    bool profiling = false;
+    std::map<std::string, KernelStat> stats;
+    std::vector<EventPair> event_pool;
+};
+
+namespace {
+
+int fail(const dan_handle* h, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, DAN_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(dan_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    HIPCHK(h, hipMalloc(&q, bytes));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return DAN_OK;
+}
+
+template <typename T>
+int dev_upload(dan_handle* h, T** p, const std::vector<T>& v) {
+    int rc = dev_alloc(h, p, v.size());
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DAN_OK;
+}
+
+bool pool_after(const dan_config& c, int l1) { return (c.pool_layers_mask >> l1) & 1u; }   // 1-based layer
+
+bool is_residual(const dan_config& c, int l1) {
+    return c.residual_start > 0 && l1 >= c.residual_start && !(l1 == c.layers && c.c_init != c.c_final);
+}
+
+void layer_dims(const dan_config& c, int l1, int* cin, int* cout, int* dil) {
+    const int in0 = 2 * EMBED + (c.use_q ? 1 : 0) + (c.use_strand ? 1 : 0) + (c.use_mask ? 3 : 0);
+    if (l1 == 1) { *cin = in0; *cout = c.c_init; *dil = 1; }
+    else if (l1 < c.layers) { *cin = c.c_init; *cout = c.c_init; *dil = c.dil_mid; }
+    else { *cin = c.c_init; *cout = c.c_final; *dil = c.dil_final; }
+}
+
+const Tensor* need(dan_handle* h, const std::string& name, std::initializer_list<int64_t> shape, int* rc) {
+    auto it = h->tensors.find(name);
+    if (it == h->tensors.end()) {
+        *rc = fail(h, DAN_ERR_MISSING_TENSOR, "missing tensor '%s'", name.c_str());
+        return nullptr;
+    }
+    const Tensor& t = it->second;
+    std::vector<int64_t> want(shape);
+    if (t.shape != want) {
+        std::string got, exp;
+        for (auto s : t.shape) got += std::to_string(s) + ",";
+        for (auto s : want) exp += std::to_string(s) + ",";
+        *rc = fail(h, DAN_ERR_SHAPE, "tensor '%s' has shape (%s) but the configuration needs (%s)", name.c_str(),
+                   got.c_str(), exp.c_str());
+        return nullptr;
+    }
+    return &t;
+}
+
+// MFMA A-fragment order for v_mfma_f32_16x16x4_f32 with the k order of a 16-channel group permuted:
+//   packed[((tap*kg + g)*tiles + n)*64 + lane][s] = W[o = 16n + (lane&15)][c = 16g + 4(lane>>4) + s][tap]
+// W(o,c,tap) is supplied by the functor (zero outside the real extents).
+template <typename F>
+std::vector<float> pack_frag(int taps, int kg, int tiles, F W) {
+    std::vector<float> out((size_t)taps * kg * tiles * 64 * 4);
+    size_t i = 0;
+    for (int t = 0; t < taps; ++t)
+        for (int g = 0; g < kg; ++g)
+            for (int n = 0; n < tiles; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) out[i++] = W(16 * n + (lane & 15), 16 * g + 4 * (lane >> 4) + s, t);
+    return out;
+}
+
+hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+int prof_begin(dan_handle* h, const char* k, hipStream_t s, EventPair* ev) {
+    if (!h->profiling) return 0;
+    if (!h->event_pool.empty()) { *ev = h->event_pool.back(); h->event_pool.pop_back(); }
+    else { HIPCHK(h, hipEventCreate(&ev->a)); HIPCHK(h, hipEventCreate(&ev->b)); }
+    HIPCHK(h, hipEventRecord(ev->a, s));
+    (void)k;
+    return 0;
+}
+
+int prof_end(dan_handle* h, const char* k, hipStream_t s, EventPair* ev) {
+    if (!h->profiling) return 0;
+    HIPCHK(h, hipEventRecord(ev->b, s));
+    h->stats[k].pending.push_back(*ev);
+    return 0;
+}
+
+int prof_collect(dan_handle* h, KernelStat& st) {
+    for (auto& ev : st.pending) {
+        HIPCHK(h, hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, ev.a, ev.b));
+        st.ms += ms;
+        st.launches += 1;
+        h->event_pool.push_back(ev);
+    }
+    st.pending.clear();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dan_abi_version(void) { return DAN_ABI_VERSION; }
+
+const char* dan_last_error(const dan_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dan_create(const dan_config* cfg, dan_t** out) {
+    if (!cfg || !out) return fail(nullptr, DAN_ERR_INVALID_ARG, "dan_create: null argument");
+    *out = nullptr;
+    const dan_config& c = *cfg;
+    if (c.layers < 1 || c.layers > DAN_MAX_LAYERS) return fail(nullptr, DAN_ERR_INVALID_ARG, "layers must be in 1..%d", DAN_MAX_LAYERS);
+    if (c.reads < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "reads must be >= 1");
+    if (c.length < 8 || c.length > MPOS)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the fp32 LDS-resident path (8..%d)", c.length, MPOS);
+    if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "channel counts must be in 1..%d", CPAD);
+    if (c.bottleneck < 0 || c.bottleneck > HPAD) return fail(nullptr, DAN_ERR_INVALID_ARG, "bottleneck must be in 0..%d", HPAD);
+    if (c.dil_mid < 1 || c.dil_mid > HALO || c.dil_final < 1 || c.dil_final > HALO)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "dilations must be in 1..%d", HALO);
+    if (c.fc_sizes[0] < 1 || c.fc_sizes[1] < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "fc_sizes must be positive");
+    if (c.residual_start == 1 || c.residual_start < 0)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "Do not allow residuals starting at conv layer %d", c.residual_start);   // model.py:209
+    if (c.precision != 0) return fail(nullptr, DAN_ERR_INVALID_ARG, "precision %d not built (0 = fp32 MFMA)", c.precision);
+    if ((c.pool_layers_mask & 1u) || (c.pool_layers_mask >> c.layers))
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "pool layers must lie in 1..layers-1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c.device_id < 0 || c.device_id >= ndev)
+        return fail(nullptr, DAN_ERR_NO_DEVICE, "no HIP device %d (found %d): the DAN forward has no CPU path", c.device_id, ndev);
+    dan_handle* h = new dan_handle();
+    h->cfg = c;
+    h->chunk = c.chunk_sites > 0 ? c.chunk_sites : 64;
+    h->max_batch = c.max_batch > 0 ? c.max_batch : 4096;
+    h->max_batch = ((h->max_batch + h->chunk - 1) / h->chunk) * h->chunk;
+    h->F = 2 * c.c_final * c.length + c.layers * c.bottleneck * c.reads;
+    h->F_stride = ((int64_t)h->F + 15) / 16 * 16;
+    h->n0_stride = (c.fc_sizes[0] + 15) / 16 * 16;
+    int b = 0;
+    for (int l1 = 1; l1 <= c.layers; ++l1)
+        if (l1 == c.layers || pool_after(c, l1)) { h->seg_begin.push_back(b); h->seg_end.push_back(l1); b = l1; }
+    h->n_segments = (int)h->seg_begin.size();
+    *out = h;
+    return DAN_OK;
+}
+
+int dan_set_tensor(dan_t* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!h || !name || !data || (ndim > 0 && !shape) || ndim < 0 || ndim > 8)
+        return fail(h, DAN_ERR_INVALID_ARG, "dan_set_tensor: bad argument");
+    if (h->finalized) return fail(h, DAN_ERR_STATE, "dan_set_tensor('%s') after dan_finalize", name);
+    Tensor t;
+    t.shape.assign(shape, shape + ndim);
+    for (auto s : t.shape)
+        if (s < 0) return fail(h, DAN_ERR_SHAPE, "tensor '%s': negative dimension", name);
+    t.data.assign(data, data + t.numel());
+    h->tensors[name] = std::move(t);
+    return DAN_OK;
+}
+
+int dan_finalize(dan_t* h) {
+    if (!h) return DAN_ERR_INVALID_ARG;
+    if (h->finalized) return fail(h, DAN_ERR_STATE, "dan_finalize called twice");
+    const dan_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device_id));
+    int rc = DAN_OK;
+    const int L = c.length, R = c.reads, H = c.bottleneck;
+
+    // ---- embeddings + positional encoding (model.py:143-145,154-162)
+    const Tensor* emb = need(h, "embeddings.weight", {VOCAB, EMBED}, &rc); if (!emb) return rc;
+    const Tensor* pe = need(h, "pe", {1, L, EMBED}, &rc); if (!pe) return rc;
+    if ((rc = dev_upload(h, &h->d_emb, emb->data))) return rc;
+    if ((rc = dev_upload(h, &h->d_pe, pe->data))) return rc;
+
+    // ---- conv stack
+    std::vector<LayerDesc> descs(c.layers);
+    std::vector<float> wc_all, bc_all((size_t)c.layers * HPAD, 0.f);
+    const size_t wc_layer = (size_t)L * 2 * 2 * 64 * 4;      // [g = 2L][tile 2][lane 64][4]
+    if (H > 0) wc_all.resize((size_t)c.layers * wc_layer);
+    // canonical position of the reference's layer-1 input channels (model.py:517,543,558,625)
+    std::vector<int> canon;
+    for (int i = 0; i < 2 * EMBED; ++i) canon.push_back(i);
+    if (c.use_q) canon.push_back(40);
+    if (c.use_strand) canon.push_back(41);
+    if (c.use_mask) { canon.push_back(42); canon.push_back(43); canon.push_back(44); }
+
+    for (int l = 0; l < c.layers; ++l) {
+        const int l1 = l + 1;
+        int cin, cout, dil;
+        layer_dims(c, l1, &cin, &cout, &dil);
+        const std::string p = "conv1D_layers." + std::to_string(l);
+        const Tensor* w = need(h, p + ".weight", {cout, cin, 1, 3}, &rc); if (!w) return rc;
+        const Tensor* b = need(h, p + ".bias", {cout}, &rc); if (!b) return rc;
+        LayerDesc& d = descs[l];
+        memset(&d, 0, sizeof d);
+        d.kg = (l == 0) ? KG0 : KGC;
+        d.dil = dil;
+        std::vector<int> inv(d.kg * 16, -1);                 // canonical channel -> reference channel
+        for (int i = 0; i < cin; ++i) inv[l == 0 ? canon[i] : i] = i;
+        auto Wf = [&](int o, int cc, int t) -> float {
+            if (o >= cout || cc >= (int)inv.size() || inv[cc] < 0) return 0.f;
+            return w->data[((size_t)o * cin + inv[cc]) * 3 + t];
+        };
+        std::vector<float> packed = pack_frag(3, d.kg, KGC, Wf);
+        float* dw = nullptr;
+        if ((rc = dev_upload(h, &dw, packed))) return rc;
+        d.w = dw;
+        std::vector<float> bias(CPAD, 0.f), scale(CPAD, 0.f), shift(CPAD, 0.f);
+        for (int o = 0; o < cout; ++o) { bias[o] = b->data[o]; scale[o] = 1.f; }
+        if (c.use_bn) {                                      // eval-mode BN after the ReLU, eps 1e-5 (model.py:750-751)
+            const std::string q = "bn1D_layers." + std::to_string(l);
+            const Tensor* g = need(h, q + ".weight", {cout}, &rc); if (!g) return rc;
+            const Tensor* be = need(h, q + ".bias", {cout}, &rc); if (!be) return rc;
+            const Tensor* mu = need(h, q + ".running_mean", {cout}, &rc); if (!mu) return rc;
+            const Tensor* var = need(h, q + ".running_var", {cout}, &rc); if (!var) return rc;
+            for (int o = 0; o < cout; ++o) {
+                const double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+                scale[o] = (float)s;
+                shift[o] = (float)((double)be->data[o] - (double)mu->data[o] * s);
+            }
+        }
+        float *dbias, *dscale, *dshift;
+        if ((rc = dev_upload(h, &dbias, bias)) || (rc = dev_upload(h, &dscale, scale)) || (rc = dev_upload(h, &dshift, shift))) return rc;
+        d.bias = dbias; d.scale = dscale; d.shift = dshift;
+        if (is_residual(c, l1)) {
+            const std::string q = "residual_conv_layers." + std::to_string(l1 - c.residual_start);   // model.py:760
+            const Tensor* wr = need(h, q + ".weight", {cout, cout, 1, 1}, &rc); if (!wr) return rc;
+            const Tensor* br = need(h, q + ".bias", {cout}, &rc); if (!br) return rc;
+            auto Wr = [&](int o, int cc, int) -> float { return (o < cout && cc < cout) ? wr->data[(size_t)o * cout + cc] : 0.f; };
+            std::vector<float> pr = pack_frag(1, KGC, KGC, Wr);
+            std::vector<float> bres(CPAD, 0.f);
+            for (int o = 0; o < cout; ++o) bres[o] = br->data[o];
+            float *dwr, *dbr;
+            if ((rc = dev_upload(h, &dwr, pr)) || (rc = dev_upload(h, &dbr, bres))) return rc;
+            d.wres = dwr; d.bres = dbr; d.residual = 1;
+        }
+        if (H > 0) {
+            const std::string q = "conv1D_bottleneck_layers." + std::to_string(l);
+            const Tensor* wb = need(h, q + ".weight", {H, cout, 1, 1}, &rc); if (!wb) return rc;
+            const Tensor* bb = need(h, q + ".bias", {H}, &rc); if (!bb) return rc;
+            auto Wb = [&](int o, int cc, int) -> float { return (o < H && cc < cout) ? wb->data[(size_t)o * cout + cc] : 0.f; };
+            std::vector<float> pb = pack_frag(1, KGC, 2, Wb);
+            std::vector<float> bbv(HPAD, 0.f);
+            for (int o = 0; o < H; ++o) bbv[o] = bb->data[o];
+            float *dwb, *dbb;
+            if ((rc = dev_upload(h, &dwb, pb)) || (rc = dev_upload(h, &dbb, bbv))) return rc;
+            d.wbot = dwb; d.bbot = dbb;
+            const std::string z = "conv1D_compression_layers." + std::to_string(l);
+            const Tensor* wcm = need(h, z + ".weight", {H, H, 1, L}, &rc); if (!wcm) return rc;
+            const Tensor* bcm = need(h, z + ".bias", {H}, &rc); if (!bcm) return rc;
+            // k = p*32 + c, k-group g = 2p + (c >> 4):  packed[g][n][lane][s] = Wc[o][c][p]
+            float* dst = wc_all.data() + (size_t)l * wc_layer;
+            size_t i = 0;
+            for (int g = 0; g < 2 * L; ++g)
+                for (int n = 0; n < 2; ++n)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s = 0; s < 4; ++s) {
+                            const int o = 16 * n + (lane & 15), cc = 16 * (g & 1) + 4 * (lane >> 4) + s, pp = g >> 1;
+                            dst[i++] = (o < H && cc < H) ? wcm->data[((size_t)o * H + cc) * L + pp] : 0.f;
+                        }
+            for (int o = 0; o < H; ++o) bc_all[(size_t)l * HPAD + o] = bcm->data[o];
+        }
+    }
+    if ((rc = dev_upload(h, &h->d_layers, descs))) return rc;
+    if (H > 0) {
+        if ((rc = dev_upload(h, &h->d_wc, wc_all)) || (rc = dev_upload(h, &h->d_bc, bc_all))) return rc;
+    }
+
+    // ---- FC stack + heads (model.py:362-377,406-415)
+    const int n0 = c.fc_sizes[0], n1 = c.fc_sizes[1];
+    const Tensor* w0 = need(h, "fc.0.weight", {n0, h->F}, &rc); if (!w0) return rc;
+    const Tensor* b0 = need(h, "fc.0.bias", {n0}, &rc); if (!b0) return rc;
+    const Tensor* w1 = need(h, "fc.1.weight", {n1, n0}, &rc); if (!w1) return rc;
+    const Tensor* b1 = need(h, "fc.1.bias", {n1}, &rc); if (!b1) return rc;
+    if ((rc = dev_alloc(h, &h->d_w0, (size_t)n0 * h->F_stride))) return rc;
+    HIPCHK(h, hipMemset(h->d_w0, 0, (size_t)n0 * h->F_stride * sizeof(float)));
+    HIPCHK(h, hipMemcpy2D(h->d_w0, h->F_stride * sizeof(float), w0->data.data(), (size_t)h->F * sizeof(float),
+                          (size_t)h->F * sizeof(float), n0, hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(h, &h->d_w1, (size_t)n1 * h->n0_stride))) return rc;
+    HIPCHK(h, hipMemset(h->d_w1, 0, (size_t)n1 * h->n0_stride * sizeof(float)));
+    HIPCHK(h, hipMemcpy2D(h->d_w1, h->n0_stride * sizeof(float), w1->data.data(), (size_t)n0 * sizeof(float),
+                          (size_t)n0 * sizeof(float), n1, hipMemcpyHostToDevice));
+    if ((rc = dev_upload(h, &h->d_b0, b0->data)) || (rc = dev_upload(h, &h->d_b1, b1->data))) return rc;
+    static const struct { const char* name; int n; } heads[] = {{"fcHidden2BinTarget", 2}, {"fcHidden2VT", 3}, {"fcHidden2AF", 1},
+                                                                 {"fcHidden2Coverage", 1}, {"fcHidden2VB", VOCAB}, {"fcHidden2VR", VOCAB}};
+    std::vector<float> wh, bh;
+    for (auto& hd : heads) {
+        const Tensor* w = need(h, std::string(hd.name) + ".weight", {hd.n, n1}, &rc); if (!w) return rc;
+        const Tensor* b = need(h, std::string(hd.name) + ".bias", {hd.n}, &rc); if (!b) return rc;
+        wh.insert(wh.end(), w->data.begin(), w->data.end());
+        bh.insert(bh.end(), b->data.begin(), b->data.end());
+    }
+    if ((rc = dev_upload(h, &h->d_wh, wh)) || (rc = dev_upload(h, &h->d_bh, bh))) return rc;
+
+    // ---- activations / workspaces, sized for one chunk (conv) and one macro-batch (FC)
+    const size_t read_floats = (size_t)L * CPAD;
+    if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pool, (size_t)h->chunk * read_floats))) return rc;
+    if (H > 0 && (rc = dev_alloc(h, &h->d_h, (size_t)c.layers * h->chunk * R * L * HPAD))) return rc;
+    if ((rc = dev_alloc(h, &h->d_feat, (size_t)h->max_batch * h->F_stride))) return rc;
+    HIPCHK(h, hipMemset(h->d_feat, 0, (size_t)h->max_batch * h->F_stride * sizeof(float)));
+    if ((rc = dev_alloc(h, &h->d_hid0, (size_t)h->max_batch * h->n0_stride)) || (rc = dev_alloc(h, &h->d_hid1, (size_t)h->max_batch * n1))) return rc;
+    HIPCHK(h, hipMemset(h->d_hid0, 0, (size_t)h->max_batch * h->n0_stride * sizeof(float)));
+    const size_t in_site = (size_t)3 * R * L + 3 * L;
+    if ((rc = dev_alloc(h, &h->d_in, (size_t)h->max_batch * in_site))) return rc;
+    if ((rc = dev_alloc(h, &h->d_out, (size_t)h->max_batch * (2 + 3 + 3 + 1 + 22)))) return rc;
+    HIPCHK(h, hipDeviceSynchronize());
+    h->tensors.clear();
+    h->finalized = true;
+    return DAN_OK;
+}
+
+void dan_destroy(dan_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& kv : h->stats) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : h->event_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    delete h;
+}
+
+int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
+                       const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
+                       float* vt_logits, float* vt_prob, float* bp, float* aux, void* stream) {
+    if (!h) return DAN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DAN_ERR_STATE, "dan_forward before dan_finalize");
+    if (n_sites < 0) return fail(h, DAN_ERR_INVALID_ARG, "negative site count");
+    if (n_sites == 0) return DAN_OK;
+    if (!reads || !qual || !strand || !ref || !ref_mask || !var_mask) return fail(h, DAN_ERR_INVALID_ARG, "null input plane");
+    const dan_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device_id));
+    hipStream_t s = as_stream(stream);
+    const int L = c.length, R = c.reads, H = c.bottleneck;
+    const size_t rl = (size_t)R * L;
+    const long long h_layer_stride = (long long)h->chunk * R * L * HPAD;
+    for (int64_t mb = 0; mb < n_sites; mb += h->max_batch) {
+        const int nb = (int)std::min<int64_t>(h->max_batch, n_sites - mb);
+        for (int c0 = 0; c0 < nb; c0 += h->chunk) {
+            const int ns = std::min(h->chunk, nb - c0);
+            const int64_t g0 = mb + c0;                      // first site of the chunk in the caller's arrays
+            for (int sg = 0; sg < h->n_segments; ++sg) {
+                SegmentArgs a{};
+                a.layers = h->d_layers;
+                a.l_begin = h->seg_begin[sg]; a.l_end = h->seg_end[sg];
+                a.R = R; a.L = L;
+                a.reads = reads + g0 * rl; a.qual = qual + g0 * rl; a.strand = strand + g0 * rl;
+                a.ref = ref + g0 * L; a.ref_mask = ref_mask + g0 * L; a.var_mask = var_mask + g0 * L;
+                a.emb = h->d_emb; a.pe = h->d_pe;
+                a.y = h->d_y;
+                a.pool = sg > 0 ? h->d_pool : nullptr;
+                a.h = h->d_h; a.h_layer_stride = h_layer_stride;
+                const bool tap_here = h->tap_layer >= 0 &&
+                                      ((h->tap_layer == 0 && sg == 0) || (h->tap_layer > a.l_begin && h->tap_layer <= a.l_end));
+                a.tap = tap_here ? h->d_tap : nullptr;
+                a.tap_layer = h->tap_layer;
+                EventPair ev{};
+                int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;
+                launch_segment(a, ns, s);
+                rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
+                if (sg + 1 < h->n_segments) {
+                    rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
+                    launch_read_mean(h->d_y, h->d_pool, ns, R, L, s);
+                    rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
+                }
+            }
+            float* feat = h->d_feat + (size_t)c0 * h->F_stride;
+            EventPair ev{};
+            int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
+            launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, s);
+            rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
+            if (H > 0) {
+                rc = prof_begin(h, "highway", s, &ev); if (rc) return rc;
+                launch_highway(h->d_h, h_layer_stride, h->d_wc, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat, h->F_stride,
+                               2 * c.c_final * L, ns, R, L, H, c.layers, s);
+                rc = prof_end(h, "highway", s, &ev); if (rc) return rc;
+            }
+            h->last_chunk_sites = ns;
+        }
+        EventPair ev{};
+        int rc = prof_begin(h, "fc", s, &ev); if (rc) return rc;
+        launch_fc(h->d_feat, h->F_stride, h->d_w0, h->F_stride, h->d_b0, h->d_hid0, h->n0_stride, nb, c.fc_sizes[0],
+                  (int)h->F_stride, 1, s);
+        launch_fc(h->d_hid0, h->n0_stride, h->d_w1, h->n0_stride, h->d_b1, h->d_hid1, c.fc_sizes[1], nb, c.fc_sizes[1],
+                  h->n0_stride, 1, s);
+        launch_heads(h->d_hid1, c.fc_sizes[1], h->d_wh, h->d_bh, nb, bin_logits ? bin_logits + mb * 2 : nullptr,
+                     vt_logits ? vt_logits + mb * 3 : nullptr, vt_prob ? vt_prob + mb * 3 : nullptr,
+                     bp ? bp + mb : nullptr, aux ? aux + mb * 22 : nullptr, s);
+        rc = prof_end(h, "fc", s, &ev); if (rc) return rc;
+        h->last_batch = nb;
+    }
+    HIPCHK(h, hipGetLastError());
+    return DAN_OK;
+}
+
+int dan_forward_aux(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
+                    const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
+                    float* vt_logits, float* vt_prob, float* bp, float* aux) {
+    if (!h) return DAN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DAN_ERR_STATE, "dan_forward before dan_finalize");
+    if (n_sites < 0) return fail(h, DAN_ERR_INVALID_ARG, "negative site count");
+    if (n_sites == 0) return DAN_OK;
+    if (!reads || !qual || !strand || !ref || !ref_mask || !var_mask) return fail(h, DAN_ERR_INVALID_ARG, "null input plane");
+    const dan_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device_id));
+    const size_t rl = (size_t)c.reads * c.length, L = c.length;
+    for (int64_t mb = 0; mb < n_sites; mb += h->max_batch) {
+        const size_t nb = (size_t)std::min<int64_t>(h->max_batch, n_sites - mb);
+        uint8_t* d = h->d_in;
+        uint8_t *dr = d, *dq = dr + nb * rl, *ds = dq + nb * rl, *df = ds + nb * rl, *drm = df + nb * L, *dvm = drm + nb * L;
+        HIPCHK(h, hipMemcpy(dr, reads + mb * rl, nb * rl, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(dq, qual + mb * rl, nb * rl, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(ds, strand + mb * rl, nb * rl, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(df, ref + mb * L, nb * L, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(drm, ref_mask + mb * L, nb * L, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(dvm, var_mask + mb * L, nb * L, hipMemcpyHostToDevice));
+        float *o_bin = h->d_out, *o_vt = o_bin + nb * 2, *o_p = o_vt + nb * 3, *o_bp = o_p + nb * 3, *o_aux = o_bp + nb;
+        int rc = dan_forward_device(h, dr, dq, ds, df, drm, dvm, (int64_t)nb, o_bin, o_vt, o_p, o_bp, o_aux, nullptr);
+        if (rc) return rc;
+        HIPCHK(h, hipDeviceSynchronize());
+        if (bin_logits) HIPCHK(h, hipMemcpy(bin_logits + mb * 2, o_bin, nb * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        if (vt_logits) HIPCHK(h, hipMemcpy(vt_logits + mb * 3, o_vt, nb * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (vt_prob) HIPCHK(h, hipMemcpy(vt_prob + mb * 3, o_p, nb * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (bp) HIPCHK(h, hipMemcpy(bp + mb, o_bp, nb * sizeof(float), hipMemcpyDeviceToHost));
+        if (aux) HIPCHK(h, hipMemcpy(aux + mb * 22, o_aux, nb * 22 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return DAN_OK;
+}
+
+int dan_forward(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
+                const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits, float* vt_logits,
+                float* vt_prob, float* bp) {
+    return dan_forward_aux(h, reads, qual, strand, ref, ref_mask, var_mask, n_sites, bin_logits, vt_logits, vt_prob, bp, nullptr);
+}
+
+int dan_set_tap(dan_t* h, int32_t layer) {
+    if (!h) return DAN_ERR_INVALID_ARG;
+    if (layer < -1 || layer > h->cfg.layers) return fail(h, DAN_ERR_INVALID_ARG, "tap layer %d out of range", layer);
+    if (layer >= 0 && !h->d_tap) {
+        if (!h->finalized) return fail(h, DAN_ERR_STATE, "dan_set_tap before dan_finalize");
+        HIPCHK(h, hipSetDevice(h->cfg.device_id));
+        int rc = dev_alloc(h, &h->d_tap, (size_t)h->chunk * h->cfg.reads * h->cfg.length * CPAD);
+        if (rc) return rc;
+    }
+    h->tap_layer = layer;
+    return DAN_OK;
+}
+
+int64_t dan_query(const dan_t* h, const char* what) {
+    if (!h || !what) return DAN_ERR_INVALID_ARG;
+    const std::string w(what);
+    if (w == "feature_width") return h->F;
+    if (w == "feature_stride") return h->F_stride;
+    if (w == "chunk_sites") return h->chunk;
+    if (w == "max_batch") return h->max_batch;
+    if (w == "cpad") return CPAD;
+    if (w == "tap_sites") return h->last_chunk_sites;
+    if (w == "segments") return h->n_segments;
+    if (w == "hidden0_stride") return h->n0_stride;
+    return fail(h, DAN_ERR_INVALID_ARG, "dan_query: unknown key '%s'", what);
+}
+
+int64_t dan_read_buffer(dan_t* h, const char* name, float* dst, int64_t capacity) {
+    if (!h || !name || !dst || capacity < 0) return DAN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DAN_ERR_STATE, "dan_read_buffer before dan_finalize");
+    const dan_config& c = h->cfg;
+    const std::string w(name);
+    const float* src = nullptr;
+    int64_t n = 0;
+    if (w == "tap") { if (!h->d_tap) return fail(h, DAN_ERR_STATE, "no tap was requested"); src = h->d_tap; n = (int64_t)h->last_chunk_sites * c.reads * c.length * CPAD; }
+    else if (w == "feature") { src = h->d_feat; n = h->last_batch * h->F_stride; }
+    else if (w == "hidden0") { src = h->d_hid0; n = h->last_batch * h->n0_stride; }
+    else if (w == "hidden1") { src = h->d_hid1; n = h->last_batch * c.fc_sizes[1]; }
+    else return fail(h, DAN_ERR_INVALID_ARG, "dan_read_buffer: unknown buffer '%s'", name);
+    n = std::min(n, capacity);
+    HIPCHK(h, hipSetDevice(c.device_id));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
+}
+
+int dan_profile_enable(dan_t* h, int32_t on) {
+    if (!h) return DAN_ERR_INVALID_ARG;
+    h->profiling = on != 0;
+    for (auto& kv : h->stats) {
+        int rc = prof_collect(h, kv.second);
+        if (rc) return rc;
+        kv.second.launches = 0;
+        kv.second.ms = 0.0;
+    }
+    return DAN_OK;
+}
+
+int dan_kernel_stats(dan_t* h, const char* kernel, int64_t* launches, double* total_ms) {
+    if (!h || !kernel) return DAN_ERR_INVALID_ARG;
+    KernelStat& st = h->stats[kernel];
+    int rc = prof_collect(h, st);
+    if (rc) return rc;
+    if (launches) *launches = st.launches;
+    if (total_ms) *total_ms = st.ms;
+    return DAN_OK;
+}
+
+}  // extern "C"

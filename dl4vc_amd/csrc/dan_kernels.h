@@ -1,0 +1,75 @@
+// Kernel-side contract shared by dan_kernels.hip (device code + launchers) and dan_capi.cpp (host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dan {
+
+// ---- fixed geometry of the fp32 path -----------------------------------------------------------
+constexpr int CPAD = 128;               // channel capacity of one activation row (c_init, c_final <= 128)
+constexpr int NWAVE = 4;                // waves per workgroup, one per SIMD
+constexpr int NT = 2;                   // 16-channel output tiles per wave   (CPAD / 16 / NWAVE)
+constexpr int MT = 13;                  // 16-position tiles per read         (L <= 208)
+constexpr int MPOS = MT * 16;           // 208
+constexpr int HALO = 4;                 // zero rows either side of the window (dilation <= 4)
+constexpr int LDS_S = 132;              // floats per LDS position row (128 + 4: conflict-light b128 reads)
+constexpr int LDS_ROWS = MPOS + 2 * HALO;   // 216
+constexpr int HPAD = 32;                // bottleneck channel capacity
+constexpr int CIN0 = 48;                // encoded input channels, padded (canonical order, see encode)
+constexpr int KG0 = CIN0 / 16;          // k-groups of layer 1
+constexpr int KGC = CPAD / 16;          // k-groups of a 128-channel layer
+constexpr int EMBED = 20;
+constexpr int VOCAB = 10;
+constexpr int NHEAD = 27;               // 2 + 3 + 1 + 1 + 10 + 10 head outputs
+
+// Per-layer constants, resident in HBM (read through the scalar / L2 path by every workgroup).
+struct LayerDesc {
+    const float* w;        // conv weights, MFMA A-fragment order: [tap][kg][tile 8][lane 64][4]
+    const float* bias;     // [CPAD]
+    const float* scale;    // [CPAD] folded BatchNorm (gamma / sqrt(var + eps)), 1 when BN is off, 0 on pad channels
+    const float* shift;    // [CPAD] beta - mean * scale
+    const float* wres;     // residual 1x1 weights [kg 8][tile 8][lane][4], or nullptr
+    const float* bres;     // [CPAD]
+    const float* wbot;     // bottleneck 1x1 weights [kg 8][tile 2][lane][4], or nullptr
+    const float* bbot;     // [HPAD]
+    int kg;                // input k-groups (KG0 for layer 1, KGC otherwise)
+    int dil;
+    int residual;
+    int pad_;
+};
+
+struct SegmentArgs {
+    const LayerDesc* layers;
+    int l_begin, l_end;          // 0-based [begin, end)
+    int R, L;
+    // segment that starts at layer 0 encodes from the uint8 planes
+    const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
+    const float* emb;            // [VOCAB][EMBED]
+    const float* pe;             // [L][EMBED]
+    // later segments start from y (+ the broadcast read-mean of the previous segment's output)
+    float* y;                    // [site][read][L][CPAD]   in/out (a workgroup only touches its own read)
+    const float* pool;           // [site][L][CPAD] or nullptr
+    float* h;                    // bottleneck outputs [layer][site][read][L][HPAD], or nullptr
+    long long h_layer_stride;    // floats between layers of h
+    float* tap;                  // [site][read][L][CPAD] or nullptr
+    int tap_layer;               // 0 = encoded input, l = after conv layer l (1-based), -1 = none
+};
+
+void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s);
+// pool[site][p][c] = mean over reads of y[site][r][p][c]          (dl4vc/model.py:772)
+void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, hipStream_t s);
+// feat[site][c*L+p] = max_r y, feat[site][C*L + c*L+p] = mean_r y   (dl4vc/model.py:824-839)
+void launch_final_pool(const float* y, float* feat, long long feat_stride, int n_sites, int R, int L, int C,
+                       hipStream_t s);
+// feat[site][off + l*H*R + o*R + r] = relu(sum_{p,c} Wc[l][o][c][p] h[l][site][r][p][c] + bc[l][o])   (model.py:776-777,859)
+void launch_highway(const float* h, long long h_layer_stride, const float* wc_packed, long long wc_layer_stride,
+                    const float* bc, float* feat, long long feat_stride, int feat_off, int n_sites, int R, int L,
+                    int H, int layers, hipStream_t s);
+// C[M][N] = relu?(A[M][lda] * W[N][ldw]^T + bias)  over K (multiple of 16)
+void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
+               long long ldc, int M, int N, int K, int relu, hipStream_t s);
+// heads + softmax: hidden [B][hid] -> logits/probabilities   (model.py:919-958, trainer.py:609-623)
+void launch_heads(const float* hidden, int hid, const float* wh /*[NHEAD][hid]*/, const float* bh, int B,
+                  float* bin_logits, float* vt_logits, float* vt_prob, float* bp, float* aux, hipStream_t s);
+
+}  // namespace dan

@@ -1,0 +1,525 @@
+// HIP kernels of the DAN inference forward for gfx950 (MI355X, CDNA4).  fp32 path.
+//
+// Hot loop: every convolution of the stack is an implicit GEMM  D[out-channel][position] +=
+// W[out-channel][k] * X[k][position]  on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  One
+// workgroup (4 waves, one per SIMD) owns ONE READ: its 201 x 128 activation lives in LDS for the
+// whole segment of layers (position-major rows of 132 floats, zero halo rows either side), each wave
+// owns 32 output channels x all 13 position tiles (104 accumulator registers), weights stream from
+// L2 straight into A fragments (host-packed in fragment order, 1 KiB coalesced per wave-load), the
+// activation B fragments come from LDS as ds_read_b128 (the K order inside a 16-channel group is
+// permuted so that one 16-byte read feeds four MFMA k-steps).  ReLU, folded BatchNorm, the 1x1
+// residual GEMM and the 128->32 highway bottleneck GEMM are fused as epilogues on the LDS-resident
+// read; only segment boundaries (the site-level read-mean of dl4vc/model.py:766-772 and the final
+// max/mean pool) and the 32-channel bottleneck outputs go to HBM.
+//
+// Reference semantics followed (file:line in /root/reference): dl4vc/model.py:450-627 (encode),
+// :728-778 (layer loop), :824-859 (pool + highway concat), :917-958 (FC + heads),
+// dl4vc/trainer.py:609-623 (softmax scores).
+#include "dan_kernels.h"
+
+namespace dan {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
+
+// ------------------------------------------------------------------------------------------------
+// implicit-GEMM core:  acc[m][n] (+)= sum_{tap,g,s} Wfrag[tap][g][n][s] * X[pos + shift(tap)][16g + 4kk + s]
+// ------------------------------------------------------------------------------------------------
+// Software pipeline: the 13 position tiles of one k-group are split in two halves (7 + 6).  While the
+// MFMAs of one half run, the ds_read_b128 of the other half (and the global load of the next k-group's
+// weight fragments) are in flight, so neither LDS nor L2 latency is exposed between MFMA blocks.
+constexpr int MTA = 7, MTB = MT - MTA;
+typedef const __attribute__((address_space(1))) v4f* gv4f_ptr;     // global (not flat) loads
+
+__device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, const v4f* __restrict__ wp_,
+                                          int kg, int ntaps, int dil, int wave, int lane) {
+    const int pos = lane & 15, kk = lane >> 4;
+    gv4f_ptr wl = (gv4f_ptr)wp_ + (wave * NT) * 64 + lane;   // + ((tap*kg + g)*8 + n)*64
+    const int total = ntaps * kg;
+    const int t0 = (ntaps == 3) ? -dil : 0;
+    const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
+    v4f a_nxt[NT], bA[MTA], bB[MTB];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) a_nxt[n] = wl[n * 64];
+    {
+        const float* xb = xrow + t0 * LDS_S;
+#pragma unroll
+        for (int m = 0; m < MTA; ++m) bA[m] = *(const v4f*)(xb + m * 16 * LDS_S);
+    }
+    int t = 0, g = 0;
+    for (int it = 0; it < total; ++it) {
+        v4f a[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a[n] = a_nxt[n];
+        const int nx = (it + 1 < total) ? it + 1 : it;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a_nxt[n] = wl[(size_t)nx * (KGC * 64) + n * 64];
+        const float* xb = xrow + (t0 + t * dil) * LDS_S + g * 16;
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) bB[m] = *(const v4f*)(xb + (MTA + m) * 16 * LDS_S);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MTA; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[n][s], bA[m][s], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        int tn = t, gn = g + 1;
+        if (gn == kg) { gn = 0; ++tn; }
+        if (it + 1 == total) { tn = t; gn = g; }             // last step: harmless re-read
+        const float* xn = xrow + (t0 + tn * dil) * LDS_S + gn * 16;
+#pragma unroll
+        for (int m = 0; m < MTA; ++m) bA[m] = *(const v4f*)(xn + m * 16 * LDS_S);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[MTA + m][n] = mfma16(a[n][s], bB[m][s], acc[MTA + m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        t = tn; g = gn;
+    }
+}
+
+// 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.
+// Position tiles are dealt round-robin to the waves (13 tiles: wave 0 takes four, the others three).
+__device__ __forceinline__ void bottleneck(const float* xs, const LayerDesc& ld, float* hrow, int L, int wave,
+                                           int lane) {
+    const int pos = lane & 15, kk = lane >> 4;
+    const v4f* wl = (const v4f*)ld.wbot + lane;
+    v4f acc[4][2];
+    const v4f b0 = *(const v4f*)(ld.bbot + kk * 4), b1 = *(const v4f*)(ld.bbot + 16 + kk * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = b0; acc[i][1] = b1; }
+    for (int g = 0; g < KGC; ++g) {
+        const v4f a0 = wl[(g * 2 + 0) * 64], a1 = wl[(g * 2 + 1) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pt = wave + 4 * i;
+            if (pt < MT) {
+                const v4f b = *(const v4f*)(xs + (HALO + pt * 16 + pos) * LDS_S + g * 16 + kk * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[i][0] = mfma16(a0[s], b[s], acc[i][0]);
+                    acc[i][1] = mfma16(a1[s], b[s], acc[i][1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pt = wave + 4 * i;
+        const int p = pt * 16 + pos;
+        if (pt < MT && p < L) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                v4f v = acc[i][n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                *(v4f*)(hrow + (size_t)p * HPAD + n * 16 + kk * 4) = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int tid) {
+    for (int i = tid; i < L * (CPAD / 4); i += 256) {
+        const int p = i >> 5, c4 = i & 31;
+        ((v4f*)dst)[i] = *(const v4f*)(xs + (HALO + p) * LDS_S + c4 * 4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// segment kernel: one workgroup = one read, layers [l_begin, l_end) with the read resident in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int site = blockIdx.x / a.R;
+    const int r = blockIdx.x - site * a.R;
+    const int L = a.L;
+    const size_t read_idx = (size_t)site * a.R + r;
+    float* yrow = a.y + read_idx * (size_t)L * CPAD;
+
+    for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += 256) ((v4f*)xs)[i] = splat(0.f);
+    __syncthreads();
+
+    if (a.l_begin == 0) {
+        // ---- encode (dl4vc/model.py:450-627): canonical 48-channel order
+        //      [read emb+pe (20) | ref emb+pe (20) | q*0.01 | strand*0.5 | refmatch | varmatch | lenmask | 0 0 0]
+        const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+        const int p = tid;
+        const bool in = p < L;
+        int tok = 0, q = 0, st = 0, rf = 0, rm = 0, vm = 0;
+        if (in) {
+            tok = a.reads[rbase + p]; q = a.qual[rbase + p]; st = a.strand[rbase + p];
+            rf = a.ref[sbase + p]; rm = a.ref_mask[sbase + p]; vm = a.var_mask[sbase + p];
+        }
+        // a read agrees with an allele iff it equals the mask wherever the mask is non-zero (model.py:592-593)
+        const int agree_ref = __syncthreads_and((rm == 0) || (tok == rm));
+        const int agree_var = __syncthreads_and((vm == 0) || (tok == vm));
+        if (in) {
+            float* row = xs + (HALO + p) * LDS_S;
+            const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
+            const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
+            const float* pp = a.pe + p * EMBED;
+#pragma unroll
+            for (int e = 0; e < EMBED; ++e) {
+                const float pv = pp[e];
+                row[e] = er[e] + pv;
+                row[EMBED + e] = ef[e] + pv;
+            }
+            row[40] = (float)q * 0.01f;                      // Q_SCORE_SCALE_FACTOR, model.py:24
+            row[41] = (float)st * 0.5f;                      // STRAND_ENCODE_FACTOR, model.py:16
+            row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
+            row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
+            row[44] = (rm != 0) ? 1.f : 0.f;                 // length mask comes from ref_masks, model.py:578-584
+        }
+    } else {
+        // ---- resume from the previous segment's output, adding the broadcast read-mean (model.py:734-742)
+        const v4f* src = (const v4f*)yrow;
+        const v4f* pl = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
+        for (int i = tid; i < L * (CPAD / 4); i += 256) {
+            const int p = i >> 5, c4 = i & 31;
+            v4f v = src[i];
+            if (pl) v += pl[i];
+            *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+    if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+
+    const int pos = lane & 15, kk = lane >> 4;
+    int chb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kk * 4;
+
+    for (int l = a.l_begin; l < a.l_end; ++l) {
+        const LayerDesc ld = a.layers[l];
+        v4f acc[MT][NT];
+        {
+            v4f bias[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bias[n] = *(const v4f*)(ld.bias + chb[n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
+        }
+        conv_gemm(acc, xs, (const v4f*)ld.w, ld.kg, 3, ld.dil, wave, lane);
+        // ---- epilogue: ReLU then eval-mode BatchNorm as one affine (model.py:749-751); rows >= L stay zero
+        {
+            v4f sc[NT], sh[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { sc[n] = *(const v4f*)(ld.scale + chb[n]); sh[n] = *(const v4f*)(ld.shift + chb[n]); }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool live = (m * 16 + pos) < L;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    v4f v = acc[m][n];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = live ? fmaxf(v[j], 0.f) * sc[n][j] + sh[n][j] : 0.f;
+                    acc[m][n] = v;
+                }
+            }
+        }
+        __syncthreads();                                    // every wave has finished reading the layer input
+        if (ld.residual) {
+            // y = W1x1 * bn(relu(conv(x))) + b + x_in   (model.py:753-761).  x_in is the layer input BEFORE
+            // the pool add (model.py:732): for the first layer of a pooled segment it is re-read from HBM.
+            v4f bres[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bres[n] = *(const v4f*)(ld.bres + chb[n]);
+            const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int p = m * 16 + pos;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    v4f* cell = (v4f*)(xs + (HALO + p) * LDS_S + chb[n]);
+                    v4f old = *cell;
+                    if (from_global) old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat(0.f);
+                    *cell = acc[m][n];
+                    acc[m][n] = old + bres[n];
+                }
+            }
+            __syncthreads();
+            conv_gemm(acc, xs, (const v4f*)ld.wres, KGC, 1, 0, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int p = m * 16 + pos;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    *(v4f*)(xs + (HALO + p) * LDS_S + chb[n]) = (p < L) ? acc[m][n] : splat(0.f);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    *(v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
+        }
+        __syncthreads();
+        if (a.tap && a.tap_layer == l + 1) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+        if (ld.wbot)
+            bottleneck(xs, ld, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+    }
+    copy_out(xs, yrow, L, tid);
+}
+
+void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s) {
+    hipLaunchKernelGGL(segment_kernel, dim3((unsigned)(n_sites * a.R)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// site-level reductions over the read axis (sequential r = 0..R-1 fp32 sums, like AvgPool2d on CPU)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void read_mean_kernel(const v4f* __restrict__ y, v4f* __restrict__ pool, int R, int L) {
+    const int n4 = L * (CPAD / 4);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int site = blockIdx.y;
+    const v4f* src = y + (size_t)site * R * n4 + i;
+    v4f sum = splat(0.f);
+    for (int r = 0; r < R; ++r) sum += src[(size_t)r * n4];
+    pool[(size_t)site * n4 + i] = sum / splat((float)R);
+}
+
+void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, hipStream_t s) {
+    const int n4 = L * (CPAD / 4);
+    hipLaunchKernelGGL(read_mean_kernel, dim3((n4 + 255) / 256, n_sites), dim3(256), 0, s, (const v4f*)y, (v4f*)pool, R, L);
+}
+
+__global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__ y, float* __restrict__ feat,
+                                                         long long fs, int R, int L, int C) {
+    __shared__ float tmax[CPAD * 17], tavg[CPAD * 17];
+    const int pt = blockIdx.x, site = blockIdx.y, tid = threadIdx.x;
+    const int c4 = tid & 31, pl = tid >> 5;
+    const int n4 = L * (CPAD / 4);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int pp = half * 8 + pl, p = pt * 16 + pp;
+        v4f mx = splat(0.f), av = splat(0.f);
+        if (p < L) {
+            const v4f* src = y + (size_t)site * R * n4 + (size_t)p * (CPAD / 4) + c4;
+            mx = src[0];
+            v4f sum = src[0];
+            for (int r = 1; r < R; ++r) {
+                const v4f v = src[(size_t)r * n4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], v[j]);
+                sum += v;
+            }
+            av = sum / splat((float)R);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tmax[(c4 * 4 + j) * 17 + pp] = mx[j];
+            tavg[(c4 * 4 + j) * 17 + pp] = av[j];
+        }
+    }
+    __syncthreads();
+    float* row = feat + (size_t)site * fs;
+    for (int idx = tid; idx < CPAD * 16; idx += 256) {
+        const int c = idx >> 4, pp = idx & 15, p = pt * 16 + pp;
+        if (c < C && p < L) {
+            row[(size_t)c * L + p] = tmax[c * 17 + pp];                         // max block first (model.py:833)
+            row[(size_t)C * L + (size_t)c * L + p] = tavg[c * 17 + pp];
+        }
+    }
+}
+
+void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, int R, int L, int C, hipStream_t s) {
+    hipLaunchKernelGGL(final_pool_kernel, dim3((L + 15) / 16, n_sites), dim3(256), 0, s, (const v4f*)y, feat, fs, R, L, C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// highway compression: per layer a GEMM  [reads of the chunk] x [L*32] x [32]   (model.py:776-777,859)
+// wave tile 32 reads x 32 outputs; k-group g = 2*p + (c>>4)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void highway_kernel(const float* __restrict__ h, long long hls,
+                                                      const v4f* __restrict__ wc, long long wcls,
+                                                      const float* __restrict__ bc, float* __restrict__ feat,
+                                                      long long fs, int feat_off, int n_rows, int R, int L, int H) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int layer = blockIdx.y;
+    const int row0 = blockIdx.x * 128 + wave * 32;
+    if (row0 >= n_rows) return;
+    const size_t K = (size_t)L * HPAD;
+    const float* hl = h + (size_t)layer * hls;
+    const v4f* wl = wc + (size_t)layer * wcls + lane;
+    const float* arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) arow[i] = hl + (size_t)min(row0 + i * 16 + r16, n_rows - 1) * K + kk * 4;
+    v4f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = splat(0.f);
+    const int G = L * 2;
+    v4f an[2], bn[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { an[i] = *(const v4f*)(arow[i]); bn[i] = wl[i * 64]; }
+    for (int g = 0; g < G; ++g) {
+        v4f a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+        const int gn = (g + 1 < G) ? g + 1 : g;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { an[i] = *(const v4f*)(arow[i] + (size_t)gn * 16); bn[i] = wl[((size_t)gn * 2 + i) * 64]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int o = j * 16 + r16;
+        if (o >= H) continue;
+        const float bias = bc[layer * HPAD + o];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int row = row0 + i * 16 + kk * 4 + jj;
+                if (row < n_rows) {
+                    const int site = row / R, r = row - site * R;
+                    feat[(size_t)site * fs + feat_off + (size_t)layer * H * R + (size_t)o * R + r] =
+                        fmaxf(acc[i][j][jj] + bias, 0.f);
+                }
+            }
+    }
+}
+
+void launch_highway(const float* h, long long hls, const float* wc, long long wcls, const float* bc, float* feat,
+                    long long fs, int feat_off, int n_sites, int R, int L, int H, int layers, hipStream_t s) {
+    const int n_rows = n_sites * R;
+    hipLaunchKernelGGL(highway_kernel, dim3((n_rows + 127) / 128, layers), dim3(256), 0, s, h, hls, (const v4f*)wc,
+                       wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FC:  C[M][N] = act(A[M][K] * W[N][K]^T + bias)   -- both operands K-contiguous (torch Linear layout)
+// workgroup tile 64 x 64 (2 x 2 waves of 32 x 32), fragments straight from L2/HBM
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ A, long long lda,
+                                                 const float* __restrict__ W, long long ldw,
+                                                 const float* __restrict__ bias, float* __restrict__ C, long long ldc,
+                                                 int M, int N, int K, int relu) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const float *ap[2], *wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ap[i] = A + (size_t)min(m0 + i * 16 + r16, M - 1) * lda + kk * 4;
+        wp[i] = W + (size_t)min(n0 + i * 16 + r16, N - 1) * ldw + kk * 4;
+    }
+    v4f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = splat(0.f);
+    const int G = K / 16;
+    v4f an[2], wn[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { an[i] = *(const v4f*)ap[i]; wn[i] = *(const v4f*)wp[i]; }
+    for (int g = 0; g < G; ++g) {
+        v4f a[2], w[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a[i] = an[i]; w[i] = wn[i]; }
+        const int gn = (g + 1 < G) ? g + 1 : g;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { an[i] = *(const v4f*)(ap[i] + (size_t)gn * 16); wn[i] = *(const v4f*)(wp[i] + (size_t)gn * 16); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i][s], w[j][s], acc[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 16 + r16;
+        if (n >= N) continue;
+        const float b = bias[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = m0 + i * 16 + kk * 4 + jj;
+                if (m < M) {
+                    float v = acc[i][j][jj] + b;
+                    if (relu) v = fmaxf(v, 0.f);
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+    }
+}
+
+void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
+               long long ldc, int M, int N, int K, int relu, hipStream_t s) {
+    hipLaunchKernelGGL(fc_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, N,
+                       K, relu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// heads + score post-processing: one 64-lane block per site
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void heads_kernel(const float* __restrict__ hidden, int hid,
+                                                   const float* __restrict__ wh, const float* __restrict__ bh,
+                                                   float* bin_logits, float* vt_logits, float* vt_prob, float* bp,
+                                                   float* aux) {
+    __shared__ float o[NHEAD];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < NHEAD) {
+        const float* x = hidden + (size_t)b * hid;
+        const float* w = wh + (size_t)t * hid;
+        float acc = 0.f;
+        for (int k = 0; k < hid; ++k) acc = fmaf(x[k], w[k], acc);
+        o[t] = acc + bh[t];
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (bin_logits) { bin_logits[b * 2] = o[0]; bin_logits[b * 2 + 1] = o[1]; }
+        if (vt_logits) { vt_logits[b * 3] = o[2]; vt_logits[b * 3 + 1] = o[3]; vt_logits[b * 3 + 2] = o[4]; }
+        if (bp) {                                            // 1 - softmax(bin)[0]   trainer.py:620-621
+            const float m = fmaxf(o[0], o[1]);
+            const float e0 = expf(o[0] - m), e1 = expf(o[1] - m);
+            bp[b] = 1.f - e0 / (e0 + e1);
+        }
+        if (vt_prob) {                                       // softmax(vt) = (NV, HV, OV)   trainer.py:623
+            const float m = fmaxf(o[2], fmaxf(o[3], o[4]));
+            const float e0 = expf(o[2] - m), e1 = expf(o[3] - m), e2 = expf(o[4] - m);
+            const float s = e0 + e1 + e2;
+            vt_prob[b * 3] = e0 / s; vt_prob[b * 3 + 1] = e1 / s; vt_prob[b * 3 + 2] = e2 / s;
+        }
+    }
+    if (aux && t < 22) {
+        float v = o[5 + t];
+        if (t == 0) v = 1.f / (1.f + expf(-v));             // sigmoid(AF)        model.py:954
+        else if (t == 1) v = v > 0.f ? v : 0.01f * v;       // leaky_relu(cov)    model.py:956
+        aux[(size_t)b * 22 + t] = v;
+    }
+}
+
+void launch_heads(const float* hidden, int hid, const float* wh, const float* bh, int B, float* bin_logits,
+                  float* vt_logits, float* vt_prob, float* bp, float* aux, hipStream_t s) {
+    hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(64), 0, s, hidden, hid, wh, bh, bin_logits, vt_logits, vt_prob, bp, aux);
+}
+
+}  // namespace dan

@@ -1,0 +1,135 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors and the oracle.  GPU only."""
+import numpy as np
+import pytest
+
+from golden_util import load_case, model_cases, input_tuple
+from dl4vc_amd.config import DanConfig
+from dl4vc_amd.model import DanNet
+from dl4vc_amd import synth
+from oracle.dan_oracle import dan_forward_oracle, random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+# north_star: softmax scores within 1e-4 of the reference fp32 forward.  The fp32-MFMA path is an exact
+# fp32 FMA chain in a different summation order, so intermediate activations are held to 1e-4 of the
+# tensor's max magnitude and the scores to 1e-4 absolute (observed: ~1e-6).
+SCORE_ATOL = 1e-4
+TAP_RTOL = 1e-4
+
+
+def cfg_from(spec) -> DanConfig:
+    keys = DanConfig.__dataclass_fields__.keys()
+    return DanConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in keys})
+
+
+def close(got, ref, tol, what):
+    scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
+    err = float(np.abs(got.astype(np.float64) - ref).max()) if ref.size else 0.0
+    assert err <= tol * scale, "%s: max abs err %.3g > %.3g" % (what, err, tol * scale)
+
+
+@pytest.mark.parametrize("case", model_cases())
+def test_golden_outputs(case):
+    spec, w, inp, out = load_case(case)
+    cfg = cfg_from(spec)
+    net = DanNet(cfg).load_state_dict(w)
+    got = net.forward_u8(*input_tuple(inp), aux=True)
+    for k in ("vt_prob", "bp"):
+        close(got[k], out[k], SCORE_ATOL, "%s:%s" % (case, k))
+    for k in ("bin_logits", "vt_logits", "af", "cov", "vb", "vr"):
+        close(got[k], out[k], TAP_RTOL, "%s:%s" % (case, k))
+    # feature / hidden taps where the fixture holds them
+    F, Fs = net.handle.query("feature_width"), net.handle.query("feature_stride")
+    B = inp["reads"].shape[0]
+    if "feature" in out:
+        feat = net.handle.read_buffer("feature", B * Fs).reshape(B, Fs)[:, :F]
+        close(feat, out["feature"], TAP_RTOL, case + ":feature")
+    if "hidden" in out:
+        hid = net.handle.read_buffer("hidden1", B * cfg.fc_sizes[1]).reshape(B, -1)
+        close(hid, out["hidden"], TAP_RTOL, case + ":hidden")
+    net.close()
+
+
+@pytest.mark.parametrize("layer", [2, 7])
+def test_golden_layer_taps(layer):
+    spec, w, inp, out = load_case("dan_small")
+    cfg = cfg_from(spec)
+    net = DanNet(cfg).load_state_dict(w)
+    net.handle.set_tap(layer)
+    net.forward_u8(*input_tuple(inp))
+    B, R, L = inp["reads"].shape
+    cpad = net.handle.query("cpad")
+    tap = net.handle.read_buffer("tap", B * R * L * cpad).reshape(B, R, L, cpad)
+    ref = out["conv%d" % layer]                      # (4, C, R, L) reference layout
+    got = np.transpose(tap[:ref.shape[0], :, :, :ref.shape[1]], (0, 3, 1, 2))
+    close(got, ref, TAP_RTOL, "conv%d" % layer)
+    assert np.all(tap[..., ref.shape[1]:] == 0), "pad channels must stay zero"
+    net.close()
+
+
+def test_reference_call_signature_roundtrip():
+    """DanNet.__call__ takes what trainer.py:569-572 passes: (B, L, R) int64 planes."""
+    import torch
+    spec, w, inp, out = load_case("dan_var_pool24")
+    net = DanNet(cfg_from(spec)).load_state_dict({"module." + k: torch.from_numpy(v) for k, v in w.items()})
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.transpose(a, (0, 2, 1)))).long()   # noqa: E731
+    res = net(t(inp["reads"]), torch.from_numpy(inp["ref"]).long(), q_scores=t(inp["qual"]), strands=t(inp["strand"]),
+              binary_trust_vector=None, af_scores=None, ref_bases=None, var_bases=None,
+              ref_masks=torch.from_numpy(inp["ref_mask"]).long(), var_masks=torch.from_numpy(inp["var_mask"]).long())
+    assert len(res) == 14 and res[6] == [] and res[10] is None
+    close(res[1], out["vt_logits"], TAP_RTOL, "vt_logits")
+    close(res[2], out["af"], TAP_RTOL, "af")
+    net.close()
+
+
+@pytest.mark.parametrize("reads", [64, 100])
+def test_production_shape_against_oracle(reads):
+    """Full-width network (128 channels, FC 1024/256) on a few sites: scores within 1e-4 of the oracle
+    (which tests/golden/full_shape_oracle_vs_reference.json pins to the reference at <= 1.2e-6)."""
+    cfg = DanConfig(reads=reads)
+    sd = random_state_dict(cfg, seed=7)
+    batch = synth.make_sites(5, reads=reads, seed=70 + reads)
+    net = DanNet(cfg).load_state_dict(sd)
+    got = net.forward_u8(*batch.arrays())
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    for k in ("vt_prob", "bp"):
+        close(got[k], want[k], SCORE_ATOL, k)
+    close(got["vt_logits"], want["vt_logits"], TAP_RTOL, "vt_logits")
+    net.close()
+
+
+def test_chunk_and_batch_boundaries_do_not_change_results():
+    """Sites are independent: any chunking of the same inputs gives bit-identical scores."""
+    cfg = DanConfig(reads=8, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))
+    sd = random_state_dict(cfg, seed=5)
+    batch = synth.make_sites(37, reads=8, seed=6)
+    a = DanNet(cfg, chunk_sites=64, max_batch=64).load_state_dict(sd)
+    b = DanNet(cfg, chunk_sites=5, max_batch=10).load_state_dict(sd)
+    ra, rb = a.forward_u8(*batch.arrays()), b.forward_u8(*batch.arrays())
+    for k in ra:
+        np.testing.assert_array_equal(ra[k], rb[k], err_msg=k)
+    # permutation of sites permutes the outputs
+    perm = np.random.default_rng(0).permutation(37)
+    rp = a.forward_u8(*[x[perm] for x in batch.arrays()])
+    np.testing.assert_array_equal(rp["vt_prob"], ra["vt_prob"][perm])
+    # empty batch
+    e = a.forward_u8(*[x[:0] for x in batch.arrays()])
+    assert e["vt_prob"].shape == (0, 3)
+    a.close(); b.close()
+
+
+def test_shape_errors_are_loud():
+    cfg = DanConfig(reads=8, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))
+    sd = random_state_dict(cfg, seed=5)
+    bad = dict(sd)
+    bad["conv1D_layers.3.weight"] = bad["conv1D_layers.3.weight"][:, :16]
+    with pytest.raises(RuntimeError, match="conv1D_layers.3.weight"):
+        DanNet(cfg).load_state_dict(bad)
+    missing = {k: v for k, v in sd.items() if k != "fcHidden2VT.bias"}
+    with pytest.raises(RuntimeError, match="fcHidden2VT.bias"):
+        DanNet(cfg).load_state_dict(missing)
+    net = DanNet(cfg).load_state_dict(sd)
+    batch = synth.make_sites(2, reads=8, seed=1)
+    with pytest.raises(ValueError):
+        net.forward_u8(batch.reads[:, :4], *batch.arrays()[1:])
+    net.close()
