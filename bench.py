@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Throughput of the DAN inference forward on MI355X  (metric of BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (dan_forward_device: encode -> conv stack -> read pooling ->
+highway -> FC -> heads -> softmax) over one synthetic batch of 65 536 candidate sites x 64 reads x 201
+columns per GPU, production network (7 x 128-channel dilated conv, FC 65 792 -> 1024 -> 256), fp32,
+seeded random weights (no checkpoint or HG002 data offline).  Inputs are resident in HBM before the
+timed region.  For N > 1 the driver launches one rank per GPU with torch.distributed.run; sites shard
+with no data-path collective -- RCCL is used only for the barrier and the
+max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, sd, batch, budget_s=20.0):
+    """The oracle (torch CPU fp32 restatement of the reference's op sequence) on the host cores:
+    a bounded sample of the same workload."""
+    import torch
+    from oracle.dan_oracle import dan_forward_oracle
+    cores = torch.get_num_threads()
+    n = 8
+    arrays = [a[:n] for a in batch.arrays()]
+    t0 = time.perf_counter()
+    dan_forward_oracle(sd, cfg, *arrays)                      # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    reps = int(max(1, min(8, (budget_s - warm) // max(warm, 1e-3))))
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dan_forward_oracle(sd, cfg, *arrays)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n / best, 3), "unit": "candidate-variants/s", "cores": int(cores), "kind": "port",
+            "sample": "%d sites x %d reads x %d bp, best of %d passes of oracle/dan_oracle.py (torch CPU fp32)"
+                      % (n, cfg.reads, cfg.length, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sites", type=int, default=65536, help="candidate sites per GPU per step")
+    ap.add_argument("--reads", type=int, default=64)
+    ap.add_argument("--chunk-sites", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from dl4vc_amd.config import DanConfig
+    from dl4vc_amd.model import DanNet
+    from dl4vc_amd import synth
+    from oracle.dan_oracle import random_state_dict        # seeded weights of the reference's shapes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the DAN forward has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = DanConfig(reads=args.reads)
+    sd = random_state_dict(cfg, seed=0)
+    net = DanNet(cfg, device_id=local_rank, chunk_sites=args.chunk_sites).load_state_dict(sd)
+
+    # synthetic inputs (seed 0 + rank), 256 distinct sites tiled to the batch on the device
+    base = synth.make_sites(256, reads=cfg.reads, seed=rank)
+    reps = -(-args.sites // 256)
+    dev = torch.device("cuda", local_rank)
+    planes = []
+    for a in base.arrays():
+        t = torch.from_numpy(a).to(dev)
+        t = t.repeat((reps,) + (1,) * (t.dim() - 1))[:args.sites].contiguous()
+        planes.append(t)
+    B = args.sites
+    outs = [torch.empty((B, 2), device=dev), torch.empty((B, 3), device=dev), torch.empty((B, 3), device=dev),
+            torch.empty((B,), device=dev)]
+    stream = torch.cuda.current_stream().cuda_stream
+    in_ptrs = [t.data_ptr() for t in planes]
+    out_ptrs = [t.data_ptr() for t in outs] + [0]
+
+    def step():
+        net.handle.forward_device(in_ptrs, B, out_ptrs, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    net.handle.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_launch, seg_ms = net.handle.kernel_stats("conv_segment")
+    net.handle.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        sites_total = B * world * args.steps
+        value = sites_total / elapsed
+        # roofline of the dominant kernel (conv-stack segment kernel): algorithmic FLOPs = 2 x MAC of every
+        # conv / residual / bottleneck GEMM it executes (the 32x32x201 highway compression runs in its own kernel)
+        macs_pos = cfg.macs_per_position() - cfg.layers * cfg.bottleneck * cfg.bottleneck
+        seg_flops_site = 2.0 * cfg.reads * cfg.length * macs_pos
+        seg_flops_total = seg_flops_site * B * args.steps
+        achieved = seg_flops_total / (seg_ms * 1e-3) / 1e12 if seg_ms > 0 else None
+        line = {
+            "metric": "candidate-variants/sec (DAN fwd, %d reads x %d bp)" % (cfg.reads, cfg.length),
+            "value": round(value, 2), "unit": "candidate-variants/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic %d sites x %d reads x %d bp per GPU per step, DAN production network "
+                                   "(7x conv128 dil2, residual 5-7, read-mean after L2, highway 32, FC %d->1024->256), "
+                                   "seeded random weights" % (B, cfg.reads, cfg.length, cfg.feature_width),
+                       "sites_per_gpu": B, "reads": cfg.reads, "window": cfg.length, "parallelism": "site-shard x%d" % world,
+                       "gflop_per_site": round(cfg.flops_per_site() / 1e9, 3)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None, "traffic": None,
+                         "kernel": "dan::segment_kernel", "launches": n_launch,
+                         "avg_launch_ms": round(seg_ms / max(n_launch, 1), 4),
+                         "gflop_per_launch": round(seg_flops_total / max(n_launch, 1) / 1e9, 3),
+                         "hbm_frac_input_bytes": round(value / world * cfg.input_bytes_per_site() / (PEAK_HBM_GBS * 1e9), 6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, base)
+        print(json.dumps(line), flush=True)
+    net.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
