@@ -49,7 +49,8 @@ struct dan_handle {
     int64_t last_batch = 0;
     // device memory
     std::vector<void*> allocs;
-    LayerDesc* d_layers = nullptr;
+    float* d_wl = nullptr;                   // [layers][LAYER_STRIDE] weight blocks
+    unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
     float *d_wc = nullptr, *d_bc = nullptr;
@@ -252,8 +253,8 @@ int dan_finalize(dan_t* h) {
     if ((rc = dev_upload(h, &h->d_emb, emb->data))) return rc;
     if ((rc = dev_upload(h, &h->d_pe, pe->data))) return rc;
 
-    // ---- conv stack
-    std::vector<LayerDesc> descs(c.layers);
+    // ---- conv stack: one fixed-stride weight block per layer (dan_kernels.h)
+    std::vector<float> wl((size_t)c.layers * LAYER_STRIDE, 0.f);
     std::vector<float> wc_all, bc_all((size_t)c.layers * HPAD, 0.f);
     const size_t wc_layer = (size_t)L * 2 * 2 * 64 * 4;      // [g = 2L][tile 2][lane 64][4]
     if (H > 0) wc_all.resize((size_t)c.layers * wc_layer);
@@ -263,30 +264,27 @@ int dan_finalize(dan_t* h) {
     if (c.use_q) canon.push_back(40);
     if (c.use_strand) canon.push_back(41);
     if (c.use_mask) { canon.push_back(42); canon.push_back(43); canon.push_back(44); }
+    h->res_mask = 0;
 
     for (int l = 0; l < c.layers; ++l) {
         const int l1 = l + 1;
         int cin, cout, dil;
         layer_dims(c, l1, &cin, &cout, &dil);
+        float* blk = wl.data() + (size_t)l * LAYER_STRIDE;
         const std::string p = "conv1D_layers." + std::to_string(l);
         const Tensor* w = need(h, p + ".weight", {cout, cin, 1, 3}, &rc); if (!w) return rc;
         const Tensor* b = need(h, p + ".bias", {cout}, &rc); if (!b) return rc;
-        LayerDesc& d = descs[l];
-        memset(&d, 0, sizeof d);
-        d.kg = (l == 0) ? KG0 : KGC;
-        d.dil = dil;
-        std::vector<int> inv(d.kg * 16, -1);                 // canonical channel -> reference channel
+        const int kg = (l == 0) ? KG0 : KGC;
+        std::vector<int> inv(kg * 16, -1);                   // canonical channel -> reference channel
         for (int i = 0; i < cin; ++i) inv[l == 0 ? canon[i] : i] = i;
         auto Wf = [&](int o, int cc, int t) -> float {
             if (o >= cout || cc >= (int)inv.size() || inv[cc] < 0) return 0.f;
             return w->data[((size_t)o * cin + inv[cc]) * 3 + t];
         };
-        std::vector<float> packed = pack_frag(3, d.kg, KGC, Wf);
-        float* dw = nullptr;
-        if ((rc = dev_upload(h, &dw, packed))) return rc;
-        d.w = dw;
-        std::vector<float> bias(CPAD, 0.f), scale(CPAD, 0.f), shift(CPAD, 0.f);
-        for (int o = 0; o < cout; ++o) { bias[o] = b->data[o]; scale[o] = 1.f; }
+        std::vector<float> packed = pack_frag(3, kg, KGC, Wf);
+        std::copy(packed.begin(), packed.end(), blk + W_OFF);
+        float* cst = blk + CST_OFF;
+        for (int o = 0; o < cout; ++o) { cst[CST_BIAS + o] = b->data[o]; cst[CST_SCALE + o] = 1.f; }
         if (c.use_bn) {                                      // eval-mode BN after the ReLU, eps 1e-5 (model.py:750-751)
             const std::string q = "bn1D_layers." + std::to_string(l);
             const Tensor* g = need(h, q + ".weight", {cout}, &rc); if (!g) return rc;
@@ -294,25 +292,20 @@ int dan_finalize(dan_t* h) {
             const Tensor* mu = need(h, q + ".running_mean", {cout}, &rc); if (!mu) return rc;
             const Tensor* var = need(h, q + ".running_var", {cout}, &rc); if (!var) return rc;
             for (int o = 0; o < cout; ++o) {
-                const double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
-                scale[o] = (float)s;
-                shift[o] = (float)((double)be->data[o] - (double)mu->data[o] * s);
+                const double sc = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+                cst[CST_SCALE + o] = (float)sc;
+                cst[CST_SHIFT + o] = (float)((double)be->data[o] - (double)mu->data[o] * sc);
             }
         }
-        float *dbias, *dscale, *dshift;
-        if ((rc = dev_upload(h, &dbias, bias)) || (rc = dev_upload(h, &dscale, scale)) || (rc = dev_upload(h, &dshift, shift))) return rc;
-        d.bias = dbias; d.scale = dscale; d.shift = dshift;
         if (is_residual(c, l1)) {
             const std::string q = "residual_conv_layers." + std::to_string(l1 - c.residual_start);   // model.py:760
             const Tensor* wr = need(h, q + ".weight", {cout, cout, 1, 1}, &rc); if (!wr) return rc;
             const Tensor* br = need(h, q + ".bias", {cout}, &rc); if (!br) return rc;
             auto Wr = [&](int o, int cc, int) -> float { return (o < cout && cc < cout) ? wr->data[(size_t)o * cout + cc] : 0.f; };
             std::vector<float> pr = pack_frag(1, KGC, KGC, Wr);
-            std::vector<float> bres(CPAD, 0.f);
-            for (int o = 0; o < cout; ++o) bres[o] = br->data[o];
-            float *dwr, *dbr;
-            if ((rc = dev_upload(h, &dwr, pr)) || (rc = dev_upload(h, &dbr, bres))) return rc;
-            d.wres = dwr; d.bres = dbr; d.residual = 1;
+            std::copy(pr.begin(), pr.end(), blk + WRES_OFF);
+            for (int o = 0; o < cout; ++o) cst[CST_BRES + o] = br->data[o];
+            h->res_mask |= 1u << l;
         }
         if (H > 0) {
             const std::string q = "conv1D_bottleneck_layers." + std::to_string(l);
@@ -320,11 +313,8 @@ int dan_finalize(dan_t* h) {
             const Tensor* bb = need(h, q + ".bias", {H}, &rc); if (!bb) return rc;
             auto Wb = [&](int o, int cc, int) -> float { return (o < H && cc < cout) ? wb->data[(size_t)o * cout + cc] : 0.f; };
             std::vector<float> pb = pack_frag(1, KGC, 2, Wb);
-            std::vector<float> bbv(HPAD, 0.f);
-            for (int o = 0; o < H; ++o) bbv[o] = bb->data[o];
-            float *dwb, *dbb;
-            if ((rc = dev_upload(h, &dwb, pb)) || (rc = dev_upload(h, &dbb, bbv))) return rc;
-            d.wbot = dwb; d.bbot = dbb;
+            std::copy(pb.begin(), pb.end(), blk + WBOT_OFF);
+            for (int o = 0; o < H; ++o) cst[CST_BBOT + o] = bb->data[o];
             const std::string z = "conv1D_compression_layers." + std::to_string(l);
             const Tensor* wcm = need(h, z + ".weight", {H, H, 1, L}, &rc); if (!wcm) return rc;
             const Tensor* bcm = need(h, z + ".bias", {H}, &rc); if (!bcm) return rc;
@@ -341,7 +331,7 @@ int dan_finalize(dan_t* h) {
             for (int o = 0; o < H; ++o) bc_all[(size_t)l * HPAD + o] = bcm->data[o];
         }
     }
-    if ((rc = dev_upload(h, &h->d_layers, descs))) return rc;
+    if ((rc = dev_upload(h, &h->d_wl, wl))) return rc;
     if (H > 0) {
         if ((rc = dev_upload(h, &h->d_wc, wc_all)) || (rc = dev_upload(h, &h->d_bc, bc_all))) return rc;
     }
@@ -421,8 +411,10 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
             const int64_t g0 = mb + c0;                      // first site of the chunk in the caller's arrays
             for (int sg = 0; sg < h->n_segments; ++sg) {
                 SegmentArgs a{};
-                a.layers = h->d_layers;
+                a.wl = h->d_wl;
                 a.l_begin = h->seg_begin[sg]; a.l_end = h->seg_end[sg];
+                a.n_layers = c.layers; a.dil_mid = c.dil_mid; a.dil_final = c.dil_final;
+                a.res_mask = h->res_mask; a.has_hw = H > 0;
                 a.R = R; a.L = L;
                 a.reads = reads + g0 * rl; a.qual = qual + g0 * rl; a.strand = strand + g0 * rl;
                 a.ref = ref + g0 * L; a.ref_mask = ref_mask + g0 * L; a.var_mask = var_mask + g0 * L;

@@ -12,7 +12,7 @@ constexpr int NT = 2;                   // 16-channel output tiles per wave   (C
 constexpr int MT = 13;                  // 16-position tiles per read         (L <= 208)
 constexpr int MPOS = MT * 16;           // 208
 constexpr int HALO = 4;                 // zero rows either side of the window (dilation <= 4)
-constexpr int LDS_S = 132;              // floats per LDS position row (128 + 4: conflict-light b128 reads)
+constexpr int LDS_S = 136;              // floats per LDS position row: 128 + 8 makes the ds_read_b128 B-fragment reads conflict-free
 constexpr int LDS_ROWS = MPOS + 2 * HALO;   // 216
 constexpr int HPAD = 32;                // bottleneck channel capacity
 constexpr int CIN0 = 48;                // encoded input channels, padded (canonical order, see encode)
@@ -22,25 +22,28 @@ constexpr int EMBED = 20;
 constexpr int VOCAB = 10;
 constexpr int NHEAD = 27;               // 2 + 3 + 1 + 1 + 10 + 10 head outputs
 
-// Per-layer constants, resident in HBM (read through the scalar / L2 path by every workgroup).
-struct LayerDesc {
-    const float* w;        // conv weights, MFMA A-fragment order: [tap][kg][tile 8][lane 64][4]
-    const float* bias;     // [CPAD]
-    const float* scale;    // [CPAD] folded BatchNorm (gamma / sqrt(var + eps)), 1 when BN is off, 0 on pad channels
-    const float* shift;    // [CPAD] beta - mean * scale
-    const float* wres;     // residual 1x1 weights [kg 8][tile 8][lane][4], or nullptr
-    const float* bres;     // [CPAD]
-    const float* wbot;     // bottleneck 1x1 weights [kg 8][tile 2][lane][4], or nullptr
-    const float* bbot;     // [HPAD]
-    int kg;                // input k-groups (KG0 for layer 1, KGC otherwise)
-    int dil;
-    int residual;
-    int pad_;
-};
+// Per-layer weight block in HBM (floats), one block per conv layer at a fixed stride so that the
+// kernel needs no per-layer descriptor loads:
+//   [W_OFF)    conv weights, MFMA A-fragment order  [tap 3][kg 8][tile 8][lane 64][4]   (layer 1 uses kg 3)
+//   [WRES_OFF) residual 1x1 weights                 [kg 8][tile 8][lane 64][4]
+//   [WBOT_OFF) bottleneck 1x1 weights               [kg 8][tile 2][lane 64][4]
+//   [CST_OFF)  bias[128] scale[128] shift[128] bres[128] bbot[32]   (scale/shift = folded eval BatchNorm)
+constexpr int W_OFF = 0;
+constexpr int WRES_OFF = W_OFF + 3 * KGC * KGC * 256;        // 49152
+constexpr int WBOT_OFF = WRES_OFF + KGC * KGC * 256;         // 65536
+constexpr int CST_OFF = WBOT_OFF + KGC * 2 * 256;            // 69632
+constexpr int CST_BIAS = 0, CST_SCALE = CPAD, CST_SHIFT = 2 * CPAD, CST_BRES = 3 * CPAD, CST_BBOT = 4 * CPAD;
+constexpr int CST_FLOATS = 4 * CPAD + HPAD;                  // 544
+constexpr int LAYER_STRIDE = CST_OFF + CST_FLOATS + 32;      // 70208 floats (16-byte aligned blocks)
+constexpr int MAX_LAYERS = 16;
 
 struct SegmentArgs {
-    const LayerDesc* layers;
+    const float* wl;             // [layers][LAYER_STRIDE]
     int l_begin, l_end;          // 0-based [begin, end)
+    int n_layers;
+    int dil_mid, dil_final;
+    unsigned res_mask;           // bit l (0-based): layer has the 1x1 residual branch
+    int has_hw;                  // highway bottleneck present
     int R, L;
     // segment that starts at layer 0 encodes from the uint8 planes
     const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;

@@ -27,29 +27,53 @@ __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
 
 __device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
 
+// Diagnostic build only (tools/seg_probe.hip defines DAN_STAMPS): per-wave s_memtime stamps of the segment
+// kernel's phases.  In the shipped library the macro expands to nothing.
+#ifdef DAN_STAMPS
+__device__ unsigned long long* g_stamps;
+constexpr int NSTAMP = 64;
+#define STAMP(k)                                                                                      \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
+        if (lane == 0 && (k) < NSTAMP) g_stamps[((size_t)blockIdx.x * NWAVE + wave) * NSTAMP + (k)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM core:  acc[m][n] (+)= sum_{tap,g,s} Wfrag[tap][g][n][s] * X[pos + shift(tap)][16g + 4kk + s]
 // ------------------------------------------------------------------------------------------------
-// Software pipeline: the 13 position tiles of one k-group are split in two halves (7 + 6).  While the
-// MFMAs of one half run, the ds_read_b128 of the other half (and the global load of the next k-group's
-// weight fragments) are in flight, so neither LDS nor L2 latency is exposed between MFMA blocks.
-constexpr int MTA = 7, MTB = MT - MTA;
+// Software pipeline: one continuous MFMA stream.  The B fragment of position tile m is single-buffered:
+// right after the eight MFMAs that consume it, the ds_read_b128 of the SAME tile for the next k-group is
+// issued, so it has twelve tiles of MFMAs (~3000 cycles) to land; the next k-group's weight fragments
+// (two 1-KiB global loads per wave) are issued at the top of the step.  sched_group_barrier pins the
+// {8 MFMA, 1 ds_read} interleave so that LDS issue never drains the matrix pipe.  The first k-group's
+// weight fragments are loaded by the caller well ahead of the call (a_first).
 typedef const __attribute__((address_space(1))) v4f* gv4f_ptr;     // global (not flat) loads
 
-__device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, const v4f* __restrict__ wp_,
-                                          int kg, int ntaps, int dil, int wave, int lane) {
+__device__ __forceinline__ float relu1(float v) {                  // one v_max_f32 (fmaxf costs two)
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+__device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, gv4f_ptr wl, const v4f (&a_first)[NT],
+                                          int kg, int ntaps, int dil, int lane) {
     const int pos = lane & 15, kk = lane >> 4;
-    gv4f_ptr wl = (gv4f_ptr)wp_ + (wave * NT) * 64 + lane;   // + ((tap*kg + g)*8 + n)*64
     const int total = ntaps * kg;
     const int t0 = (ntaps == 3) ? -dil : 0;
     const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
-    v4f a_nxt[NT], bA[MTA], bB[MTB];
+    v4f a_nxt[NT], b[MT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) a_nxt[n] = wl[n * 64];
+    for (int n = 0; n < NT; ++n) a_nxt[n] = a_first[n];
     {
         const float* xb = xrow + t0 * LDS_S;
 #pragma unroll
-        for (int m = 0; m < MTA; ++m) bA[m] = *(const v4f*)(xb + m * 16 * LDS_S);
+        for (int m = 0; m < MT; ++m) b[m] = *(const v4f*)(xb + m * 16 * LDS_S);
     }
     int t = 0, g = 0;
     for (int it = 0; it < total; ++it) {
@@ -59,72 +83,91 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, c
         const int nx = (it + 1 < total) ? it + 1 : it;
 #pragma unroll
         for (int n = 0; n < NT; ++n) a_nxt[n] = wl[(size_t)nx * (KGC * 64) + n * 64];
-        const float* xb = xrow + (t0 + t * dil) * LDS_S + g * 16;
-#pragma unroll
-        for (int m = 0; m < MTB; ++m) bB[m] = *(const v4f*)(xb + (MTA + m) * 16 * LDS_S);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int m = 0; m < MTA; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[n][s], bA[m][s], acc[m][n]);
-        __builtin_amdgcn_sched_barrier(0);
         int tn = t, gn = g + 1;
         if (gn == kg) { gn = 0; ++tn; }
         if (it + 1 == total) { tn = t; gn = g; }             // last step: harmless re-read
         const float* xn = xrow + (t0 + tn * dil) * LDS_S + gn * 16;
 #pragma unroll
-        for (int m = 0; m < MTA; ++m) bA[m] = *(const v4f*)(xn + m * 16 * LDS_S);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int m = 0; m < MTB; ++m)
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[n][s], b[m][s], acc[m][n]);
+            b[m] = *(const v4f*)(xn + m * 16 * LDS_S);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);         // the weight loads first
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[MTA + m][n] = mfma16(a[n][s], bB[m][s], acc[MTA + m][n]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < MT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // 8 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+        }
         t = tn; g = gn;
     }
 }
 
-// 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.
-// Position tiles are dealt round-robin to the waves (13 tiles: wave 0 takes four, the others three).
-__device__ __forceinline__ void bottleneck(const float* xs, const LayerDesc& ld, float* hrow, int L, int wave,
-                                           int lane) {
+// 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.  26 output
+// tiles (13 position tiles x 2 channel tiles): wave w owns position tiles {w, w+4, w+8} x both channel
+// tiles, and position tile 12 is split by channel tile between waves 0/1 (waves 2/3 shadow them so that
+// every wave runs the same seven-tile stream; only the owners store).
+__device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC][2], const float* bbot, float* hrow,
+                                           int L, int wave, int lane) {
     const int pos = lane & 15, kk = lane >> 4;
-    const v4f* wl = (const v4f*)ld.wbot + lane;
-    v4f acc[4][2];
-    const v4f b0 = *(const v4f*)(ld.bbot + kk * 4), b1 = *(const v4f*)(ld.bbot + 16 + kk * 4);
+    const bool odd = wave & 1;
+    const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
+    v4f acc[3][2], acc7, b[4];
+    {
+        const v4f b0 = *(const v4f*)(bbot + kk * 4), b1 = *(const v4f*)(bbot + 16 + kk * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i][0] = b0; acc[i][1] = b1; }
-    for (int g = 0; g < KGC; ++g) {
-        const v4f a0 = wl[(g * 2 + 0) * 64], a1 = wl[(g * 2 + 1) * 64];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pt = wave + 4 * i;
-            if (pt < MT) {
-                const v4f b = *(const v4f*)(xs + (HALO + pt * 16 + pos) * LDS_S + g * 16 + kk * 4);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[i][0] = mfma16(a0[s], b[s], acc[i][0]);
-                    acc[i][1] = mfma16(a1[s], b[s], acc[i][1]);
-                }
-            }
-        }
+        for (int i = 0; i < 3; ++i) { acc[i][0] = b0; acc[i][1] = b1; }
+        acc7 = odd ? b1 : b0;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pt = wave + 4 * i;
-        const int p = pt * 16 + pos;
-        if (pt < MT && p < L) {
+    for (int i = 0; i < 3; ++i) b[i] = *(const v4f*)(xrow + (wave + 4 * i) * 16 * LDS_S);
+    b[3] = *(const v4f*)(xrow + 12 * 16 * LDS_S);
+#pragma unroll
+    for (int g = 0; g < KGC; ++g) {
+        const int gn = (g + 1 < KGC) ? g + 1 : g;
+        const v4f a7 = odd ? wf[g][1] : wf[g][0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[i][0] = mfma16(wf[g][0][s], b[i][s], acc[i][0]);
+                acc[i][1] = mfma16(wf[g][1][s], b[i][s], acc[i][1]);
+            }
+            b[i] = *(const v4f*)(xrow + (wave + 4 * i) * 16 * LDS_S + gn * 16);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc7 = mfma16(a7[s], b[3][s], acc7);
+        b[3] = *(const v4f*)(xrow + 12 * 16 * LDS_S + gn * 16);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = (wave + 4 * i) * 16 + pos;
+        if (p < L) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 v4f v = acc[i][n];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
                 *(v4f*)(hrow + (size_t)p * HPAD + n * 16 + kk * 4) = v;
             }
+        }
+    }
+    {
+        const int p = 12 * 16 + pos;
+        if (wave < 2 && p < L) {
+            v4f v = acc7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
+            *(v4f*)(hrow + (size_t)p * HPAD + wave * 16 + kk * 4) = v;
         }
     }
 }
@@ -141,6 +184,7 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
+    __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,8 +193,24 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
     const int L = a.L;
     const size_t read_idx = (size_t)site * a.R + r;
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
+    const int pos = lane & 15, kk = lane >> 4;
+    int chb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kk * 4;
 
+    STAMP(0);
+    // first conv's first weight fragments: in flight during the whole prologue
+    v4f pre_conv[NT];
+    {
+        gv4f_ptr w0 = (gv4f_ptr)(a.wl + (size_t)a.l_begin * LAYER_STRIDE + W_OFF) + (wave * NT) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pre_conv[n] = w0[n * 64];
+    }
     for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += 256) ((v4f*)xs)[i] = splat(0.f);
+    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += 256) {
+        const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
+        cst[i] = a.wl[(size_t)(a.l_begin + l) * LAYER_STRIDE + CST_OFF + j];
+    }
     __syncthreads();
 
     if (a.l_begin == 0) {
@@ -188,80 +248,142 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
         // ---- resume from the previous segment's output, adding the broadcast read-mean (model.py:734-742)
         const v4f* src = (const v4f*)yrow;
         const v4f* pl = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
-        for (int i = tid; i < L * (CPAD / 4); i += 256) {
-            const int p = i >> 5, c4 = i & 31;
-            v4f v = src[i];
-            if (pl) v += pl[i];
-            *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = v;
+        // a single CU streams at (bytes in flight) / latency: put the whole read (and the pool image) in flight
+        // at once -- 26 + 26 sixteen-byte loads per lane -- instead of a few loads per round trip
+        const int n4 = L * (CPAD / 4);
+        constexpr int NP = MPOS * (CPAD / 4) / 256;          // 26
+        v4f vy[NP], vp[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * 256;
+            vy[k] = (i < n4) ? src[i] : splat(0.f);
+        }
+        if (pl) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * 256;
+                vp[k] = (i < n4) ? pl[i] : splat(0.f);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) vp[k] = splat(0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * 256;
+            if (i < n4) *(v4f*)(xs + (HALO + (i >> 5)) * LDS_S + (i & 31) * 4) = vy[k] + vp[k];
         }
     }
     __syncthreads();
+    STAMP(1);
     if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
 
-    const int pos = lane & 15, kk = lane >> 4;
-    int chb[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kk * 4;
-
     for (int l = a.l_begin; l < a.l_end; ++l) {
-        const LayerDesc ld = a.layers[l];
+        const float* wblk = a.wl + (size_t)l * LAYER_STRIDE;
+        const float* lc = cst + (l - a.l_begin) * CST_FLOATS;
+        const bool residual = (a.res_mask >> l) & 1u;
+        const int kg = (l == 0) ? KG0 : KGC;
+        const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
+        gv4f_ptr w_conv = (gv4f_ptr)(wblk + W_OFF) + (wave * NT) * 64 + lane;
+        gv4f_ptr w_res = (gv4f_ptr)(wblk + WRES_OFF) + (wave * NT) * 64 + lane;
+        gv4f_ptr w_bot = (gv4f_ptr)(wblk + WBOT_OFF) + lane;
+        // first fragments of the later GEMM stages of this layer and of the next conv: loaded now, used after
+        // the conv GEMM, so their L2 latency is never exposed
+        v4f pre_res[NT], pre_next[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            pre_res[n] = residual ? w_res[n * 64] : splat(0.f);
+            pre_next[n] = (l + 1 < a.l_end) ? w_conv[(size_t)(LAYER_STRIDE / 4) + n * 64] : splat(0.f);
+        }
+
         v4f acc[MT][NT];
         {
             v4f bias[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bias[n] = *(const v4f*)(ld.bias + chb[n]);
+            for (int n = 0; n < NT; ++n) bias[n] = *(const v4f*)(lc + CST_BIAS + chb[n]);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
         }
-        conv_gemm(acc, xs, (const v4f*)ld.w, ld.kg, 3, ld.dil, wave, lane);
+        [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+        STAMP(sb + 0);
+        conv_gemm(acc, xs, w_conv, pre_conv, kg, 3, dil, lane);
+        STAMP(sb + 1);
+        // all sixteen bottleneck weight fragments of this layer: issued now, consumed after the epilogue
+        // (and the residual GEMM), so the ~1.5k-cycle loaded-L2 latency is off the critical path
+        v4f wbot[KGC][2];
+        if (a.has_hw) {
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) { wbot[g][0] = w_bot[(g * 2) * 64]; wbot[g][1] = w_bot[(g * 2 + 1) * 64]; }
+        }
         // ---- epilogue: ReLU then eval-mode BatchNorm as one affine (model.py:749-751); rows >= L stay zero
         {
             v4f sc[NT], sh[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) { sc[n] = *(const v4f*)(ld.scale + chb[n]); sh[n] = *(const v4f*)(ld.shift + chb[n]); }
+            for (int n = 0; n < NT; ++n) { sc[n] = *(const v4f*)(lc + CST_SCALE + chb[n]); sh[n] = *(const v4f*)(lc + CST_SHIFT + chb[n]); }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const bool live = (m * 16 + pos) < L;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     v4f v = acc[m][n];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = live ? fmaxf(v[j], 0.f) * sc[n][j] + sh[n][j] : 0.f;
+                    for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]) * sc[n][j] + sh[n][j];
                     acc[m][n] = v;
+                }
+                if ((m + 1) * 16 > L) {                      // wave-uniform: only tiles that cross the window end
+                    const bool live = (m * 16 + pos) < L;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat(0.f);
                 }
             }
         }
+        STAMP(sb + 2);
         __syncthreads();                                    // every wave has finished reading the layer input
-        if (ld.residual) {
+        STAMP(sb + 3);
+        if (residual) {
             // y = W1x1 * bn(relu(conv(x))) + b + x_in   (model.py:753-761).  x_in is the layer input BEFORE
             // the pool add (model.py:732): for the first layer of a pooled segment it is re-read from HBM.
             v4f bres[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bres[n] = *(const v4f*)(ld.bres + chb[n]);
+            for (int n = 0; n < NT; ++n) bres[n] = *(const v4f*)(lc + CST_BRES + chb[n]);
             const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
+            if (!from_global) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int p = m * 16 + pos;
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    v4f* cell = (v4f*)(xs + (HALO + p) * LDS_S + chb[n]);
-                    v4f old = *cell;
-                    if (from_global) old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat(0.f);
-                    *cell = acc[m][n];
-                    acc[m][n] = old + bres[n];
+                    for (int n = 0; n < NT; ++n) {
+                        v4f* cell = (v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]);
+                        const v4f old = *cell;
+                        *cell = acc[m][n];
+                        acc[m][n] = old + bres[n];
+                    }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int p = m * 16 + pos;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const v4f old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat(0.f);
+                        *(v4f*)(xs + (HALO + p) * LDS_S + chb[n]) = acc[m][n];
+                        acc[m][n] = old + bres[n];
+                    }
                 }
             }
             __syncthreads();
-            conv_gemm(acc, xs, (const v4f*)ld.wres, KGC, 1, 0, wave, lane);
+            STAMP(sb + 4);
+            conv_gemm(acc, xs, w_res, pre_res, KGC, 1, 0, lane);
+            STAMP(sb + 5);
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int p = m * 16 + pos;
+                if ((m + 1) * 16 > L) {
+                    const bool live = (m * 16 + pos) < L;
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    *(v4f*)(xs + (HALO + p) * LDS_S + chb[n]) = (p < L) ? acc[m][n] : splat(0.f);
+                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat(0.f);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) *(v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
             }
         } else {
 #pragma unroll
@@ -271,11 +393,18 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
                     *(v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
         }
         __syncthreads();
+        STAMP(sb + 6);
         if (a.tap && a.tap_layer == l + 1) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
-        if (ld.wbot)
-            bottleneck(xs, ld, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+        if (a.has_hw)
+            bottleneck(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave,
+                       lane);
+        STAMP(sb + 7);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pre_conv[n] = pre_next[n];
     }
+    STAMP(62);
     copy_out(xs, yrow, L, tid);
+    STAMP(63);
 }
 
 void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s) {

@@ -1,0 +1,72 @@
+// Diagnostic build of the conv-stack segment kernel with per-phase s_memtime stamps (never shipped,
+// never timed for throughput: stamps serialise the schedule -- read the SHARES, not the length).
+//   hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/seg_probe.hip -o /tmp/seg_probe && /tmp/seg_probe [l_begin l_end]
+#include "../dl4vc_amd/csrc/dan_kernels.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+using namespace dan;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int l_begin = argc > 2 ? atoi(argv[1]) : 2, l_end = argc > 2 ? atoi(argv[2]) : 7;
+    const int R = 64, L = 201, sites = 64, layers = 7, nwg = sites * R;
+    std::vector<float> wl((size_t)layers * LAYER_STRIDE);
+    srand(1);
+    for (auto& v : wl) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+    float *d_wl, *d_y, *d_pool, *d_h, *d_emb, *d_pe;
+    uint8_t* d_u8;
+    CK(hipMalloc(&d_wl, wl.size() * 4));
+    CK(hipMemcpy(d_wl, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
+    const size_t ny = (size_t)nwg * L * CPAD;
+    std::vector<float> y(ny);
+    for (auto& v : y) v = rand() / (float)RAND_MAX - 0.5f;
+    CK(hipMalloc(&d_y, ny * 4));
+    CK(hipMemcpy(d_y, y.data(), ny * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_pool, (size_t)sites * L * CPAD * 4));
+    CK(hipMemcpy(d_pool, y.data(), (size_t)sites * L * CPAD * 4, hipMemcpyHostToDevice));
+    const size_t hls = (size_t)nwg * L * HPAD;
+    CK(hipMalloc(&d_h, hls * layers * 4));
+    CK(hipMalloc(&d_emb, VOCAB * EMBED * 4)); CK(hipMemset(d_emb, 0, VOCAB * EMBED * 4));
+    CK(hipMalloc(&d_pe, L * EMBED * 4)); CK(hipMemset(d_pe, 0, L * EMBED * 4));
+    CK(hipMalloc(&d_u8, (size_t)nwg * L)); CK(hipMemset(d_u8, 1, (size_t)nwg * L));
+    unsigned long long* d_st;
+    const size_t nst = (size_t)nwg * NWAVE * NSTAMP;
+    CK(hipMalloc(&d_st, nst * 8)); CK(hipMemset(d_st, 0, nst * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof d_st));
+    SegmentArgs a{};
+    a.wl = d_wl; a.l_begin = l_begin; a.l_end = l_end; a.n_layers = layers; a.dil_mid = 2; a.dil_final = 2;
+    a.res_mask = 0x70; a.has_hw = 1; a.R = R; a.L = L;
+    a.reads = a.qual = a.strand = a.ref = a.ref_mask = a.var_mask = d_u8;
+    a.emb = d_emb; a.pe = d_pe; a.y = d_y; a.pool = l_begin ? d_pool : nullptr; a.h = d_h; a.h_layer_stride = (long long)hls;
+    a.tap = nullptr; a.tap_layer = -1;
+    for (int rep = 0; rep < 3; ++rep) { launch_segment(a, sites, 0); CK(hipDeviceSynchronize()); }
+    std::vector<unsigned long long> st(nst);
+    CK(hipMemcpy(st.data(), d_st, nst * 8, hipMemcpyDeviceToHost));
+    // median over workgroups/waves of each phase delta
+    auto med = [&](int k0, int k1, int wave_sel) {
+        std::vector<long long> d;
+        for (int wg = 0; wg < nwg; ++wg)
+            for (int w = 0; w < NWAVE; ++w) {
+                if (wave_sel >= 0 && w != wave_sel) continue;
+                const unsigned long long* s = &st[((size_t)wg * NWAVE + w) * NSTAMP];
+                if (s[k0] && s[k1]) d.push_back((long long)(s[k1] - s[k0]));
+            }
+        if (d.empty()) return -1LL;
+        std::sort(d.begin(), d.end());
+        return d[d.size() / 2];
+    };
+    printf("segment [%d,%d)  median cycles (all waves | wave0 | wave3)\n", l_begin, l_end);
+    printf("prologue (zero+load)        %8lld\n", med(0, 1, -1));
+    for (int l = l_begin; l < l_end; ++l) {
+        const int sb = 2 + (l - l_begin) * 8;
+        printf("L%d  pre(const/init) %7lld | conv %7lld %7lld %7lld | epi %6lld | barrier %6lld | swap %6lld | res %7lld | write+bar %6lld | bottleneck %6lld %6lld %6lld\n",
+               l + 1, med(l == l_begin ? 1 : sb - 1, sb, -1), med(sb, sb + 1, -1), med(sb, sb + 1, 0), med(sb, sb + 1, 3),
+               med(sb + 1, sb + 2, -1), med(sb + 2, sb + 3, -1), med(sb + 3, sb + 4, -1), med(sb + 4, sb + 5, -1),
+               med(((a.res_mask >> l) & 1) ? sb + 5 : sb + 3, sb + 6, -1), med(sb + 6, sb + 7, -1), med(sb + 6, sb + 7, 0), med(sb + 6, sb + 7, 3));
+    }
+    printf("copy_out                    %8lld\n", med(62, 63, -1));
+    printf("total                       %8lld\n", med(0, 63, -1));
+    return 0;
+}
