@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Drop-in for the inference-only mode of the reference's ``main.py`` (main.py:47-229, branch :213-222).
+
+    python main.py <the flags call_variants.sh passes> --test_file X.hdf --modelload CKPT \
+        --save_vcf_records --save_vcf_records_file OUT/model_test.vcf --sample_vcf OUT/candidates.vcf
+
+Reads the candidate HDF5 (schema of tools/convert_bam_single_reads.py), scores every site with the
+MI355X-native DAN forward and writes ``OUT/epoch1_model_test.vcf`` exactly where and how the reference does
+(dl4vc/utils.py:146-178).  ``--gpus N`` starts one process per GPU over contiguous site shards and
+concatenates the part files on the host; there is no collective on this path.  Training flags are parsed
+(the pipeline script passes them) and ignored; ``--train_file`` is rejected: training is out of scope.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from arguments import create_arg_parser                       # noqa: E402
+
+
+def main(argv=None) -> int:
+    args = create_arg_parser().parse_args(argv)
+    print(args)
+    if args.train_file:
+        raise SystemExit("training (--train_file) is outside this implementation's scope (inference hot path only)")
+    assert args.test_file[-3:] == "hdf", "Test dataset must be in HDF format"                     # main.py:84
+    print("\n\nRunning in inference only mode...\n\n")
+    assert args.modelload is not None, "--modelload argument is required when running in inference only mode"   # main.py:215
+    from dl4vc_amd.config import DanConfig
+    from dl4vc_amd.shard import parse_shard, part_path, concat_parts
+    from dl4vc_amd.vcf import scored_vcf_path, start_scored_vcf
+
+    cfg = DanConfig.from_args(args)                           # rejects unsupported model options loudly
+    shard_i, shard_n = parse_shard(args.shard)
+    if args.save_vcf_records:
+        assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"
+    out_base = args.save_vcf_records_file or os.path.join(os.path.dirname(args.test_file), "model_test.vcf")
+    out_final = scored_vcf_path(out_base)                     # <dir>/epoch1_<basename>, dl4vc/utils.py:152
+
+    if args.gpus > 1 and not args.shard:
+        # one process per GPU, contiguous shards, host-side concat
+        t0 = time.time()
+        procs = []
+        for g in range(args.gpus):
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=str(g), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            cmd = [sys.executable, os.path.abspath(__file__)] + list(argv or sys.argv[1:]) + ["--shard", "%d/%d" % (g, args.gpus)]
+            procs.append(subprocess.Popen(cmd, env=env))
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise SystemExit("shard process failed: %s" % rcs)
+        concat_parts(out_final, args.gpus, header_from=args.sample_vcf)
+        print("\tTime elapsed for inference/testing {:.4f}".format(time.time() - t0))
+        return 0
+
+    from dl4vc_amd.model import DanNet, load_checkpoint
+    from dl4vc_amd.inference import run_shard
+
+    s_eval = time.time()
+    print("Loading model checkpoint from {}".format(args.modelload))
+    net = DanNet(cfg, device_id=0, max_batch=args.sites_per_launch).load_state_dict(load_checkpoint(args.modelload))
+    if shard_n > 1:
+        target = part_path(out_final, shard_i)
+    else:
+        target = out_final + ".records"
+    n = run_shard(net, args.test_file, target, shard_i, shard_n, sites_per_launch=args.sites_per_launch,
+                  reads_seed=args.reads_seed, use_var_type_threshold=args.use_var_type_threshold,
+                  max_batches=args.max_test_batches, log=lambda m: print(m, end="\r"))
+    net.close()
+    if shard_n == 1:
+        if args.sample_vcf:
+            start_scored_vcf(args.sample_vcf, out_base)
+        else:
+            open(out_final, "w").close()
+        with open(out_final, "a") as out, open(target) as src:
+            out.write(src.read())
+        os.remove(target)
+    print("\nscored %d sites -> %s" % (n, out_final if shard_n == 1 else target))
+    print("\tTime elapsed for inference/testing {:.4f}".format(time.time() - s_eval))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -448,16 +448,36 @@ def gen_vcf_fixtures(u):
     print("wrote vcf.json (%d format_vcf scenarios)" % len(fmt))
 
 
+def gen_cli_fixture():
+    """The reference's flag table (arguments.py:5-135): option strings, type, default, nargs, required."""
+    import importlib
+    ref_args_mod = importlib.import_module("arguments")
+    assert ref_args_mod.__file__.startswith(REF), ref_args_mod.__file__
+    parser = ref_args_mod.create_arg_parser()
+    table = []
+    for a in parser._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        table.append({"flags": a.option_strings, "dest": a.dest, "type": getattr(a.type, "__name__", None),
+                      "default": a.default, "nargs": a.nargs, "required": a.required,
+                      "store_true": type(a).__name__ == "_StoreTrueAction"})
+    with open(os.path.join(GOLD, "cli_flags.json"), "w") as f:
+        json.dump(table, f, indent=0)
+    print("wrote cli_flags.json (%d flags)" % len(table))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     m, d, u = import_reference()
-    which = sys.argv[1:] or ["model", "dataset", "vcf"]
+    which = sys.argv[1:] or ["model", "dataset", "vcf", "cli"]
     if "model" in which:
         gen_model_fixtures(m)
     if "dataset" in which:
         gen_dataset_fixtures(d, u)
     if "vcf" in which:
         gen_vcf_fixtures(u)
+    if "cli" in which:
+        gen_cli_fixture()
 
 
 if __name__ == "__main__":

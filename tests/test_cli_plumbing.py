@@ -1,0 +1,186 @@
+"""CLI surface, HDF5 reader and the inference harness on CPU (BASELINE config 1: 1k-site plumbing).
+
+The HIP forward cannot run here, so the harness is driven with a test double whose ``forward_u8`` is the
+oracle -- test infrastructure only; the product CLI itself refuses to run without the extension + GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from dl4vc_amd import synth, hdf5io, vcf
+from dl4vc_amd.config import DanConfig
+from dl4vc_amd.inference import score_records, run_shard
+from dl4vc_amd.shard import shard_range, parse_shard, concat_parts, part_path
+from oracle.dan_oracle import dan_forward_oracle, random_state_dict
+
+
+class OracleNet:
+    """Test double with DanNet's calling surface, backed by the CPU oracle."""
+    def __init__(self, cfg, sd):
+        self.config, self.sd = cfg, sd
+
+    def forward_u8(self, *planes, aux=False):
+        return dan_forward_oracle(self.sd, self.config, *planes)
+
+
+SMALL = DanConfig(reads=8, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8))
+
+
+@pytest.fixture(scope="module")
+def hdf_1k(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cfg1")
+    base = synth.make_sites(250, reads=8, seed=21)
+    batch = synth.tile_sites(base, 1000)
+    recs = hdf5io.records_from_sites(batch, store_reads=200)
+    # distinct positions so that the later sort is well defined
+    for i in range(1000):
+        f = batch.vcfrec[i].split("\t")
+        f[1] = str(100000 + 7 * i)
+        recs[i]["vcfrec"] = "\t".join(f).encode()
+    path = str(d / "candidates.hdf")
+    hdf5io.write_candidates(path, recs)
+    sample = str(d / "candidates.vcf")
+    open(sample, "w").write("##fileformat=VCFv4.2\n##source=test\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n")
+    return path, sample, recs
+
+
+def test_cli_flags_match_reference():
+    import sys
+    sys.path.insert(0, ROOT)
+    from arguments import create_arg_parser
+    ref = json.load(open(os.path.join(GOLDEN, "cli_flags.json")))
+    ours = {a.dest: a for a in create_arg_parser()._actions if a.option_strings}
+    for f in ref:
+        a = ours.get(f["dest"])
+        assert a is not None, f["flags"]
+        assert a.option_strings == f["flags"]
+        # argparse's type=None parses to str, so an untyped reference flag (--sample_vcf) equals type=str
+        assert (getattr(a.type, "__name__", None) or "str") == (f["type"] or ("str" if not f["store_true"] else None) or "str") \
+            or f["store_true"], f["flags"]
+        assert a.default == f["default"], f["flags"]
+        assert a.nargs == f["nargs"] and a.required == f["required"], f["flags"]
+        assert (type(a).__name__ == "_StoreTrueAction") == f["store_true"]
+
+
+def test_call_variants_flag_line_parses():
+    """Every flag call_variants.sh:101-147 passes must parse and map to the production configuration."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from arguments import create_arg_parser
+    line = ("--lr 0.0002 --grad-clip 1.0 --label-smoothing 0.001 --model-hidden-dropout 0.1 --model-batchnorm "
+            "--num-data-workers 5 --trust-snp-only --non-snp-train-weight 2.0 --fp-train-weight 0.2 --model-use-q-scores "
+            "--model-use-strands --auxillary-loss-weight 1.0 --auxillary-loss-bases-weight 0.01 "
+            "--auxillary-loss-allele-weight 0.001 --loss-debug-freq 10000 --aux-keep-candidate-af "
+            "--model-use-reads-ref-var-mask --close_match_window 2.0 --focal_loss_alpha 1. --focal_loss_gamma 0.2 "
+            "--model-conv-layers 7 --model-residual-layer-start 5 --model-ave-pool-layers 2 --early_loss_weight 0.1 "
+            "--model-init-conv-channels 128 --rm_var_reads_rate 0.0 --rm_non_var_reads_rate 0.0 "
+            "--close_examples_sample_rate 0.15 --delay_augmentation_epochs 1 --learn_early_loss_weight "
+            "--model_pool_combine_dimension 0 --model-final-conv-channels 128 --model-bottleneck-size 32 "
+            "--model_final_layer_dilation 2 --model_middle_layer_dilation 2 --model_concat_hw_reads "
+            "--model-highway-single-reads --log-interval 1 --model-batchnorm --gpus 1 --test-batch-size 200 "
+            "--save_vcf_records --save_vcf_records_file out/model_test.vcf --test_file out/candidates.hdf "
+            "--sample_vcf out/candidates.vcf --modelload ckpt.pth.tar").split()
+    args = create_arg_parser().parse_args(line)
+    assert DanConfig.from_args(args) == DanConfig()           # the only published configuration
+
+
+def test_hdf5_schema_roundtrip(hdf_1k):
+    path, _, recs = hdf_1k
+    with hdf5io.CandidateFile(path) as f:
+        assert len(f) == 1000 and f.dtype.itemsize == 123965
+        got = f.read(990, 2000)
+        assert len(got) == 10
+        np.testing.assert_array_equal(got.view(np.uint8), recs[990:].view(np.uint8))
+        assert len(f.read(5, 5)) == 0
+
+
+def test_config1_plumbing_end_to_end(hdf_1k, tmp_path):
+    """HDF5 -> scored VCF -> sort -> format_vcf: order, %.8f formatting, genotypes."""
+    path, sample, recs = hdf_1k
+    net = OracleNet(SMALL, random_state_dict(SMALL, seed=2))
+    out = vcf.start_scored_vcf(sample, str(tmp_path / "model_test.vcf"))
+    assert os.path.basename(out) == "epoch1_model_test.vcf"
+    with hdf5io.CandidateFile(path) as src, open(out, "a") as f:
+        n = score_records(net, src, f.write, sites_per_launch=300)
+    assert n == 1000
+    lines = open(out).read().splitlines()
+    body = [l for l in lines if not l.startswith("#")]
+    assert len(lines) - len(body) == 3 and len(body) == 1000
+    # record order is the file order and the ID column carries the four scores with 8 decimals
+    for i in (0, 499, 999):
+        cols = body[i].split("\t")
+        assert cols[1] == str(100000 + 7 * i)
+        keys = [kv.split("=")[0] for kv in cols[2].split(";")]
+        assert keys == ["BP", "NV", "HV", "OV"] and all(len(kv.split("=")[1].split(".")[1]) == 8 for kv in cols[2].split(";"))
+    # batching changes nothing but the CPU oracle's last-bit rounding (torch CPU GEMMs are not batch-invariant;
+    # the HIP path is, bit for bit -- tests/test_hip_parity.py::test_chunk_and_batch_boundaries...)
+    out2 = str(tmp_path / "again.vcf")
+    with hdf5io.CandidateFile(path) as src, open(out2, "w") as f:
+        score_records(net, src, f.write, sites_per_launch=1000)
+    body2 = open(out2).read().splitlines()
+    assert [l.split("\t")[:2] + l.split("\t")[3:] for l in body2] == [l.split("\t")[:2] + l.split("\t")[3:] for l in body]
+    sc = lambda l: np.array([float(kv.split("=")[1]) for kv in l.split("\t")[2].split(";")])   # noqa: E731
+    assert max(np.abs(sc(a) - sc(b)).max() for a, b in zip(body, body2)) < 1e-5
+    # genotype stage on the (already position-sorted) file
+    called = vcf.format_vcf_lines([l + "\n" for l in lines], vcf.FormatOptions(**vcf.PIPELINE_OPTIONS))
+    gts = [l.rstrip("\n").split("\t")[-1].split(":")[0] for l in called if not l.startswith("#")]
+    assert set(gts) <= {"0/1", "1/1"} and len(gts) <= 1000
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 7, 1000, 65536):
+        for g in (1, 2, 3, 8):
+            spans = [shard_range(n, i, g) for i in range(g)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert parse_shard("") == (0, 1) and parse_shard("3/8") == (3, 8)
+    with pytest.raises(ValueError):
+        parse_shard("8/8")
+
+
+def _rank_main(rank, world, path, out, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = OracleNet(SMALL, random_state_dict(SMALL, seed=2))
+    run_shard(net, path, part_path(out, rank), rank, world, sites_per_launch=100)
+    dist.barrier()                         # the only cross-rank step: parts are complete before the concat
+    if rank == 0:
+        concat_parts(out, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_equals_single_process(hdf_1k, tmp_path):
+    """world_size 2 over gloo: sites shard with no data-path collective; host-side concat == 1-process output."""
+    import torch.multiprocessing as mp
+    path, _, _ = hdf_1k
+    single = str(tmp_path / "single.vcf")
+    # launches of 100 sites fall on the same boundaries with 1 and 2 shards, so even the CPU oracle's
+    # batch-dependent rounding is identical and the files must match byte for byte
+    run_shard(OracleNet(SMALL, random_state_dict(SMALL, seed=2)), path, single, 0, 1, sites_per_launch=100)
+    multi = str(tmp_path / "multi.vcf")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(2, path, multi, port), nprocs=2, join=True)
+    assert open(multi).read() == open(single).read()
+    assert not os.path.exists(part_path(multi, 0))
+
+
+def test_cli_refuses_without_gpu(hdf_1k, tmp_path):
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    path, sample, _ = hdf_1k
+    ck = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: torch.from_numpy(v) for k, v in random_state_dict(SMALL, seed=2).items()}}, ck)
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--test_file", path, "--modelload", ck, "--sample_vcf", sample,
+           "--save_vcf_records", "--save_vcf_records_file", str(tmp_path / "model_test.vcf"), "--model-conv-layers", "7",
+           "--model-residual-layer-start", "5", "--model-batchnorm", "--model-use-q-scores", "--model-use-strands",
+           "--model-use-reads-ref-var-mask", "--model-highway-single-reads", "--model_concat_hw_reads",
+           "--model_pool_combine_dimension", "0", "--model_middle_layer_dilation", "2", "--model_final_layer_dilation", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and ("no CPU path" in r.stderr or "no HIP device" in r.stderr)
