@@ -33,7 +33,10 @@ def cpu_baseline(cfg, sd, batch, budget_s=20.0):
     a bounded sample of the same workload."""
     import torch
     from oracle.dan_oracle import dan_forward_oracle
-    cores = torch.get_num_threads()
+    # the GPU box grants one GPU's share of the host (16 hardware threads); oversubscribing torch's intra-op
+    # pool across all 256 visible threads is slower than using the share
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
     n = 8
     arrays = [a[:n] for a in batch.arrays()]
     t0 = time.perf_counter()

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Drop-in for the INFERENCE STAGES of the reference's call_variants.sh (call_variants.sh:99-168): scoring of
+# an existing candidates.hdf with the MI355X-native DAN forward, then sort, genotype thresholds and (when the
+# tools exist) bcftools multi-allele join + bgzip/tabix.  The BAM -> candidates.vcf -> candidates.hdf stages
+# (pysam pileup, reference call_variants.sh:76-97) are CPU pre-processing outside this implementation: run
+# them with the reference's tools, or pass an existing OUTDIR that already holds candidates.{vcf,hdf}.
+set -e
+usage() { echo "Usage: $0 -m MODEL -o OUTDIR [-g GPUS]   (OUTDIR must hold candidates.hdf and candidates.vcf)"; exit 1; }
+GPUS=1
+while getopts "m:o:g:h" opt; do
+  case $opt in
+    m) MODEL=$OPTARG ;;
+    o) OUTDIR=$OPTARG ;;
+    g) GPUS=$OPTARG ;;
+    *) usage ;;
+  esac
+done
+[ -z "$MODEL" ] || [ -z "$OUTDIR" ] && usage
+SCRIPTDIR="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+[ -f "$OUTDIR/candidates.hdf" ] || { echo "missing $OUTDIR/candidates.hdf"; exit 1; }
+
+printf "Run inference...\n"
+python "$SCRIPTDIR/main.py" \
+    --model-hidden-dropout 0.1 --model-batchnorm --model-use-q-scores --model-use-strands \
+    --model-use-reads-ref-var-mask --model-conv-layers 7 --model-residual-layer-start 5 \
+    --model-ave-pool-layers 2 --model-init-conv-channels 128 --model-final-conv-channels 128 \
+    --model_pool_combine_dimension 0 --model-bottleneck-size 32 --model_final_layer_dilation 2 \
+    --model_middle_layer_dilation 2 --model_concat_hw_reads --model-highway-single-reads \
+    --gpus "$GPUS" --test-batch-size 200 --save_vcf_records \
+    --save_vcf_records_file "$OUTDIR/model_test.vcf" --test_file "$OUTDIR/candidates.hdf" \
+    --sample_vcf "$OUTDIR/candidates.vcf" --modelload "$MODEL" > "$OUTDIR/training.log" 2>&1
+
+printf "Sort output VCF...\n"
+awk '$1 ~ /^#/ {print $0;next} {print $0 | "sort -k1,1 -k2,2n"}' "$OUTDIR/epoch1_model_test.vcf" > "$OUTDIR/model_test_sorted.vcf"
+
+printf "Threshold and combine multi-allele...\n"
+python "$SCRIPTDIR/tools/format_vcf.py" --input_file "$OUTDIR/model_test_sorted.vcf" \
+    --output_file "$OUTDIR/model_test_sorted_thres.vcf" --snp_threshold 0.1 --indel_threshold 0.2 \
+    --snp_zygo_threshold 0.75 --indel_zygo_threshold 0.8 > "$OUTDIR/format_vcf.log" 2>&1
+
+if command -v bcftools >/dev/null 2>&1; then
+  bcftools norm -m +any "$OUTDIR/model_test_sorted_thres.vcf" > "$OUTDIR/model_test_sorted_thres-join.vcf" 2> "$OUTDIR/bcftools_norm.log"
+  sed -i 's/0\/2/1\/2/' "$OUTDIR/model_test_sorted_thres-join.vcf"
+  sed -i 's/2\/2/1\/2/' "$OUTDIR/model_test_sorted_thres-join.vcf"
+  bgzip -c "$OUTDIR/model_test_sorted_thres-join.vcf" > "$OUTDIR/called_variants.vcf.gz"
+  tabix -p vcf "$OUTDIR/called_variants.vcf.gz"
+  echo "Called variants in $OUTDIR/called_variants.vcf.gz"
+else
+  echo "bcftools not found: stopping at $OUTDIR/model_test_sorted_thres.vcf"
+fi

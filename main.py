@@ -47,7 +47,9 @@ def main(argv=None) -> int:
         t0 = time.time()
         procs = []
         for g in range(args.gpus):
-            env = dict(os.environ, HIP_VISIBLE_DEVICES=str(g), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            # DL4VC_FORCE_DEVICE0: rehearse the multi-process path on a one-GPU box (tests)
+            dev = "0" if os.environ.get("DL4VC_FORCE_DEVICE0") else str(g)
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=dev, HSA_ENABLE_IPC_MODE_LEGACY="0")
             cmd = [sys.executable, os.path.abspath(__file__)] + list(argv or sys.argv[1:]) + ["--shard", "%d/%d" % (g, args.gpus)]
             procs.append(subprocess.Popen(cmd, env=env))
         rcs = [p.wait() for p in procs]

@@ -1,0 +1,73 @@
+"""main.py end to end on the GPU: HDF5 in, epoch1_*.vcf out, scores checked against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from dl4vc_amd import synth, hdf5io
+from dl4vc_amd.config import DanConfig
+from oracle.dan_oracle import dan_forward_oracle, random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+MODEL_FLAGS = ["--model-conv-layers", "7", "--model-residual-layer-start", "5", "--model-batchnorm", "--model-use-q-scores",
+               "--model-use-strands", "--model-use-reads-ref-var-mask", "--model-highway-single-reads",
+               "--model_concat_hw_reads", "--model_pool_combine_dimension", "0", "--model_middle_layer_dilation", "2",
+               "--model_final_layer_dilation", "2", "--model-hidden-dropout", "0.1"]
+
+
+def _scores(line):
+    return np.array([float(kv.split("=")[1]) for kv in line.split("\t")[2].split(";")])
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_main_py_inference(tmp_path, gpus):
+    import torch
+    cfg = DanConfig()                                   # production structure, 100 reads
+    sd = random_state_dict(cfg, seed=12)
+    ck = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"epoch": 3, "best_loss": 0.0, "optimizer": {},
+                "state_dict": {"module." + k: torch.from_numpy(v) for k, v in sd.items()}}, ck)
+    batch = synth.make_sites(24, reads=100, seed=31)
+    recs = hdf5io.records_from_sites(batch)
+    # two deep pileups (> 100 stored reads): the read subset is pinned by --reads-seed
+    rng = np.random.default_rng(0)
+    for i in (3, 17):
+        recs[i]["num_reads"] = 160
+        recs[i]["single_reads"][100:160] = recs[i]["single_reads"][rng.integers(0, 100, 60)]
+    hdf = str(tmp_path / "candidates.hdf")
+    hdf5io.write_candidates(hdf, recs)
+    sample = str(tmp_path / "candidates.vcf")
+    open(sample, "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n")
+    out = str(tmp_path / "model_test.vcf")
+    env = dict(os.environ)
+    if gpus == 2:
+        # one physical GPU on the test box: both shard processes use device 0
+        env["DL4VC_FORCE_DEVICE0"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--test_file", hdf, "--modelload", ck, "--sample_vcf", sample,
+           "--save_vcf_records", "--save_vcf_records_file", out, "--gpus", str(gpus), "--reads-seed", "77",
+           "--sites-per-launch", "16"] + MODEL_FLAGS
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(str(tmp_path / "epoch1_model_test.vcf")).read().splitlines()
+    assert lines[0].startswith("##fileformat") and lines[1].startswith("#CHROM")
+    body = lines[2:]
+    assert len(body) == 24
+    # oracle on the same assembled sites (same pinned subsets: seed + absolute record index)
+    from dl4vc_amd.dataset import assemble_batch
+    with hdf5io.CandidateFile(hdf) as f:
+        full = []
+        for b0 in range(0, 24, 16):
+            full.append(assemble_batch(f.read(b0, b0 + 16), 100, seed=77 + b0))
+    want_vt, want_bp = [], []
+    for b in full:
+        o = dan_forward_oracle(sd, cfg, *b.arrays())
+        want_vt.append(o["vt_prob"]); want_bp.append(o["bp"])
+    want_vt, want_bp = np.concatenate(want_vt), np.concatenate(want_bp)
+    for i, line in enumerate(body):
+        s = _scores(line)
+        assert abs(s[0] - want_bp[i]) < 1e-4 and np.abs(s[1:] - want_vt[i]).max() < 1e-4, (i, s, want_bp[i], want_vt[i])
+        assert line.split("\t")[1] == batch.vcfrec[i].split("\t")[1]
