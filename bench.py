@@ -131,6 +131,13 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        # HBM traffic of the dominant kernel: measured by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+        # of this same command and committed under profiles/ (PMC collection cannot run inside the timed process)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.isfile(tpath) and cfg.reads == 64 and not args.chunk_sites:
+            with open(tpath) as f:
+                traffic = int(json.load(f)["segment_kernel_bytes_per_launch"]["total"])
         sites_total = B * world * args.steps
         value = sites_total / elapsed
         # roofline of the dominant kernel (conv-stack segment kernel): algorithmic FLOPs = 2 x MAC of every
@@ -151,7 +158,7 @@ def main():
                        "gflop_per_site": round(cfg.flops_per_site() / 1e9, 3)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None, "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None, "traffic": traffic,
                          "kernel": "dan::segment_kernel", "launches": n_launch,
                          "avg_launch_ms": round(seg_ms / max(n_launch, 1), 4),
                          "gflop_per_launch": round(seg_flops_total / max(n_launch, 1) / 1e9, 3),
