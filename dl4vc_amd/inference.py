@@ -46,8 +46,47 @@ def score_records(net, source: CandidateFile, write: Callable[[str], None], lo: 
     return done
 
 
-def run_shard(net, hdf_path: str, out_path: str, shard_index: int = 0, shard_count: int = 1, **kw) -> int:
+def score_file_native(net, hdf_path: str, write: Callable[[str], None], lo: int, hi: int, sites_per_launch: int = 4096,
+                      reads_seed: int = 0, use_var_type_threshold: bool = False, max_batches: int = 0, log=None,
+                      threads: int = 0) -> int:
+    """Same contract as ``score_records`` but fed by the native batched loader (dl4vc_amd/loader.py): chunk
+    inflate and site assembly of batch k+1.. run in C++ threads while the GPU scores batch k."""
+    import os
+    from .loader import NativeLoader
+    cfg = net.config
+    threads = threads or max(2, min(16, (os.cpu_count() or 4)))
+    done, batches = 0, 0
+    t0 = time.perf_counter()
+    with NativeLoader(hdf_path, cfg.reads, batch_sites=sites_per_launch, lo=lo, hi=hi, seed=reads_seed,
+                      threads=threads) as nl:
+        for batch in nl:
+            if max_batches > 0 and batches > max_batches:
+                break
+            if not cfg.use_q:
+                batch.qual[:] = 0
+            if not cfg.use_strand:
+                batch.strand[:] = 0
+            out = net.forward_u8(*batch.arrays())
+            vt = out["vt_prob"]
+            bp = (1.0 - vt[:, 0]) if use_var_type_threshold else out["bp"]
+            write("".join(scored_record(r, b, v) + "\n" for r, b, v in zip(batch.vcfrec, bp, vt)))
+            done += len(batch)
+            batches += 1
+            if log:
+                dt = time.perf_counter() - t0
+                log("  scored %d/%d sites (%.0f sites/s)" % (done, hi - lo, done / max(dt, 1e-9)))
+    return done
+
+
+def run_shard(net, hdf_path: str, out_path: str, shard_index: int = 0, shard_count: int = 1, native: bool = True,
+              **kw) -> int:
     """Score this rank's contiguous slice into ``out_path`` (records only, no header)."""
-    with CandidateFile(hdf_path) as src, open(out_path, "w") as f:
-        lo, hi = shard_range(len(src), shard_index, shard_count)
-        return score_records(net, src, f.write, lo, hi, **kw)
+    from . import loader
+    with CandidateFile(hdf_path) as src:
+        n = len(src)
+    lo, hi = shard_range(n, shard_index, shard_count)
+    with open(out_path, "w") as f:
+        if native and loader.available():
+            return score_file_native(net, hdf_path, f.write, lo, hi, **kw)
+        with CandidateFile(hdf_path) as src:
+            return score_records(net, src, f.write, lo, hi, **kw)
