@@ -275,7 +275,8 @@ struct dl_loader {
     size_t itemsize = 0;
     size_t off_reads = 0, off_ref = 0, off_num = 0, off_vcf = 0, off_q = 0, off_strand = 0;
     int store_rows = 0, L = 201, R = 100;
-    int batch = 0;
+    int batch = 0;                  // sites per dl_next call
+    int piece = 0;                  // sites per worker task (divides batch): parallelism is per piece, not per batch
     uint64_t seed = 0;
     bool use_seed = false;
     int64_t chunk_records = 0;      // 0 = not chunked (or unsupported filter): hyperslab reads
@@ -335,7 +336,7 @@ bool read_records(dl_loader* l, int64_t lo, int64_t hi, std::vector<uint8_t>& ou
 
 std::unique_ptr<Batch> build_batch(dl_loader* l, int64_t b) {
     std::unique_ptr<Batch> out(new Batch());
-    const int64_t first = l->lo + b * l->batch, last = std::min(l->hi, first + l->batch);
+    const int64_t first = l->lo + b * l->piece, last = std::min(l->hi, first + l->piece);
     const int n = (int)(last - first), R = l->R, L = l->L;
     out->first = first; out->n = n;
     std::vector<uint8_t> recs;
@@ -483,10 +484,12 @@ int dl_open(const char* path, const char* libhdf5_path, int32_t reads, int64_t l
     l->hi = hi < 0 ? l->n_records : std::min(hi, l->n_records);
     if (l->hi < l->lo) l->hi = l->lo;
     l->batch = batch_sites;
+    l->piece = 1;
+    for (int d = 1; d <= 128 && d <= batch_sites; ++d) if (batch_sites % d == 0) l->piece = d;
     l->seed = seed; l->use_seed = use_seed != 0;
-    l->n_batches = (l->hi - l->lo + batch_sites - 1) / batch_sites;
-    l->prefetch = std::max(1, prefetch);
+    l->n_batches = (l->hi - l->lo + l->piece - 1) / l->piece;          // counted in pieces
     const int nt = std::max(1, std::min(threads, 64));
+    l->prefetch = std::max(std::max(1, prefetch) * (batch_sites / l->piece), 2 * nt);
     dl_loader* raw = l.release();
     for (int i = 0; i < nt; ++i) raw->workers.emplace_back(worker_main, raw);
     *out = raw;
@@ -500,28 +503,32 @@ int32_t dl_window(const dl_loader_t* l) { return l ? l->L : -1; }
 int64_t dl_next(dl_loader_t* l, uint8_t* reads, uint8_t* qual, uint8_t* strand, uint8_t* ref, uint8_t* ref_mask,
                 uint8_t* var_mask, char* vcfrec, int32_t* num_reads, uint8_t* blacklist) {
     if (!l) return -1;
-    if (l->next_deliver >= l->n_batches) return 0;
-    std::unique_ptr<Batch> b;
-    {
-        std::unique_lock<std::mutex> g(l->q_mutex);
-        l->cv_done.wait(g, [&] { return l->ready.count(l->next_deliver) > 0; });
-        b = std::move(l->ready[l->next_deliver]);
-        l->ready.erase(l->next_deliver);
-        l->next_deliver++;
+    const size_t rl = (size_t)l->R * l->L;
+    size_t filled = 0;
+    while (filled < (size_t)l->batch && l->next_deliver < l->n_batches) {
+        std::unique_ptr<Batch> b;
+        {
+            std::unique_lock<std::mutex> g(l->q_mutex);
+            l->cv_done.wait(g, [&] { return l->ready.count(l->next_deliver) > 0; });
+            b = std::move(l->ready[l->next_deliver]);
+            l->ready.erase(l->next_deliver);
+            l->next_deliver++;
+        }
+        l->cv_space.notify_all();
+        if (!b->error.empty()) { l->err = b->error; return -2; }
+        const size_t n = (size_t)b->n;
+        if (reads) memcpy(reads + filled * rl, b->reads.data(), n * rl);
+        if (qual) memcpy(qual + filled * rl, b->qual.data(), n * rl);
+        if (strand) memcpy(strand + filled * rl, b->strand.data(), n * rl);
+        if (ref) memcpy(ref + filled * l->L, b->ref.data(), n * l->L);
+        if (ref_mask) memcpy(ref_mask + filled * l->L, b->rmask.data(), n * l->L);
+        if (var_mask) memcpy(var_mask + filled * l->L, b->vmask.data(), n * l->L);
+        if (vcfrec) memcpy(vcfrec + filled * 129, b->vcf.data(), n * 129);
+        if (num_reads) memcpy(num_reads + filled, b->nreads.data(), n * sizeof(int32_t));
+        if (blacklist) memcpy(blacklist + filled, b->black.data(), n);
+        filled += n;
     }
-    l->cv_space.notify_all();
-    if (!b->error.empty()) { l->err = b->error; return -2; }
-    const size_t rl = (size_t)l->R * l->L, n = (size_t)b->n;
-    if (reads) memcpy(reads, b->reads.data(), n * rl);
-    if (qual) memcpy(qual, b->qual.data(), n * rl);
-    if (strand) memcpy(strand, b->strand.data(), n * rl);
-    if (ref) memcpy(ref, b->ref.data(), n * l->L);
-    if (ref_mask) memcpy(ref_mask, b->rmask.data(), n * l->L);
-    if (var_mask) memcpy(var_mask, b->vmask.data(), n * l->L);
-    if (vcfrec) memcpy(vcfrec, b->vcf.data(), n * 129);
-    if (num_reads) memcpy(num_reads, b->nreads.data(), n * sizeof(int32_t));
-    if (blacklist) memcpy(blacklist, b->black.data(), n);
-    return (int64_t)n;
+    return (int64_t)filled;
 }
 
 void dl_close(dl_loader_t* l) {
