@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; the bf16x3 path issues 3 MFMAs per algorithmic product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -63,6 +64,8 @@ def main():
     ap.add_argument("--reads", type=int, default=64)
     ap.add_argument("--chunk-sites", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="0 fp32 MFMA (headline), 1 bf16x3 split, 2 bf16")
+    ap.add_argument("--window", type=int, default=201)
     args = ap.parse_args()
 
     import torch
@@ -85,12 +88,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = DanConfig(reads=args.reads)
+    cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision)
     sd = random_state_dict(cfg, seed=0)
     net = DanNet(cfg, device_id=local_rank, chunk_sites=args.chunk_sites).load_state_dict(sd)
 
     # synthetic inputs (seed 0 + rank), 256 distinct sites tiled to the batch on the device
-    base = synth.make_sites(256, reads=cfg.reads, seed=rank)
+    base = synth.make_sites(256, reads=cfg.reads, length=cfg.length, seed=rank)
     reps = -(-args.sites // 256)
     dev = torch.device("cuda", local_rank)
     planes = []
@@ -135,7 +138,7 @@ def main():
         # of this same command and committed under profiles/ (PMC collection cannot run inside the timed process)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.isfile(tpath) and cfg.reads == 64 and not args.chunk_sites:
+        if os.path.isfile(tpath) and cfg.reads == 64 and not args.chunk_sites and cfg.precision == 0 and cfg.length == 201:
             with open(tpath) as f:
                 traffic = int(json.load(f)["segment_kernel_bytes_per_launch"]["total"])
         sites_total = B * world * args.steps
@@ -146,19 +149,20 @@ def main():
         seg_flops_site = 2.0 * cfg.reads * cfg.length * macs_pos
         seg_flops_total = seg_flops_site * B * args.steps
         achieved = seg_flops_total / (seg_ms * 1e-3) / 1e12 if seg_ms > 0 else None
+        peak = PEAK_F32_MFMA_TFLOPS if cfg.precision == 0 else PEAK_BF16_MFMA_TFLOPS
         line = {
             "metric": "candidate-variants/sec (DAN fwd, %d reads x %d bp)" % (cfg.reads, cfg.length),
             "value": round(value, 2), "unit": "candidate-variants/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("f32", "bf16x3", "bf16")[cfg.precision], "data": "synthetic",
             "config": {"workload": "synthetic %d sites x %d reads x %d bp per GPU per step, DAN production network "
                                    "(7x conv128 dil2, residual 5-7, read-mean after L2, highway 32, FC %d->1024->256), "
                                    "seeded random weights" % (B, cfg.reads, cfg.length, cfg.feature_width),
                        "sites_per_gpu": B, "reads": cfg.reads, "window": cfg.length, "parallelism": "site-shard x%d" % world,
                        "gflop_per_site": round(cfg.flops_per_site() / 1e9, 3)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None, "traffic": traffic,
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
                          "kernel": "dan::segment_kernel", "launches": n_launch,
                          "avg_launch_ms": round(seg_ms / max(n_launch, 1), 4),
                          "gflop_per_launch": round(seg_flops_total / max(n_launch, 1) / 1e9, 3),

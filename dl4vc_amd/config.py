@@ -18,7 +18,9 @@ MAX_READS = 100
 MIN_RESIDUAL_LAYER = 2
 MAX_LAYERS = 16       # capacity of the C-ABI config struct (include/dl4vc_dan.h)
 
-PRECISION_F32 = 0     # v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (parity path)
+PRECISION_F32 = 0     # v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (parity path, the default)
+PRECISION_BF16X3 = 1  # split-bf16: hi+lo operands, three bf16 MFMAs per product, fp32 accumulate (L <= 208)
+PRECISION_BF16 = 2    # plain bf16 operands, fp32 accumulate (BASELINE config 5: 128 reads x 301 bp; L <= 304)
 
 
 class UnsupportedModelOption(ValueError):

@@ -49,7 +49,8 @@ struct dan_handle {
     int64_t last_batch = 0;
     // device memory
     std::vector<void*> allocs;
-    float* d_wl = nullptr;                   // [layers][LAYER_STRIDE] weight blocks
+    float* d_wl = nullptr;                   // [layers][LAYER_STRIDE] weight blocks (fp32 path)
+    char* d_wl16 = nullptr;                  // [layers][W16_LAYER_BYTES] bf16 hi/lo weight blocks (precision 1, 2)
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
@@ -151,6 +152,33 @@ std::vector<float> pack_frag(int taps, int kg, int tiles, F W) {
 
 hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// fp32 -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does); NaN stays NaN
+uint16_t bf16_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_float(uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; }
+
+// MFMA 16x16x32 bf16 A-fragment order, hi plane then lo plane (lo = bf16(w - hi)):
+//   plane[((tap*kg + g)*tiles + n)*64 + lane][j] = W[o = 16n + (lane&15)][c = 32g + 8(lane>>4) + j][tap]
+template <typename F>
+void pack_frag16(uint16_t* dst, size_t plane_frags, int taps, int kg, int tiles, F W) {
+    size_t i = 0;
+    for (int t = 0; t < taps; ++t)
+        for (int g = 0; g < kg; ++g)
+            for (int n = 0; n < tiles; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j, ++i) {
+                        const float w = W(16 * n + (lane & 15), 32 * g + 8 * (lane >> 4) + j, t);
+                        const uint16_t hi = bf16_bits(w);
+                        dst[i] = hi;
+                        dst[plane_frags * 8 + i] = bf16_bits(w - bf16_float(hi));
+                    }
+}
+
 int prof_begin(dan_handle* h, const char* k, hipStream_t s, EventPair* ev) {
     if (!h->profiling) return 0;
     if (!h->event_pool.empty()) { *ev = h->event_pool.back(); h->event_pool.pop_back(); }
@@ -194,8 +222,11 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     const dan_config& c = *cfg;
     if (c.layers < 1 || c.layers > DAN_MAX_LAYERS) return fail(nullptr, DAN_ERR_INVALID_ARG, "layers must be in 1..%d", DAN_MAX_LAYERS);
     if (c.reads < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "reads must be >= 1");
-    if (c.length < 8 || c.length > MPOS)
-        return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the fp32 LDS-resident path (8..%d)", c.length, MPOS);
+    if (c.precision < 0 || c.precision > 2)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "precision %d unknown (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)", c.precision);
+    const int max_len = c.precision == 2 ? MT_MAX16 * 16 : MPOS;
+    if (c.length < 8 || c.length > max_len)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the LDS-resident path at precision %d (8..%d)", c.length, c.precision, max_len);
     if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "channel counts must be in 1..%d", CPAD);
     if (c.bottleneck < 0 || c.bottleneck > HPAD) return fail(nullptr, DAN_ERR_INVALID_ARG, "bottleneck must be in 0..%d", HPAD);
@@ -204,7 +235,6 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     if (c.fc_sizes[0] < 1 || c.fc_sizes[1] < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "fc_sizes must be positive");
     if (c.residual_start == 1 || c.residual_start < 0)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "Do not allow residuals starting at conv layer %d", c.residual_start);   // model.py:209
-    if (c.precision != 0) return fail(nullptr, DAN_ERR_INVALID_ARG, "precision %d not built (0 = fp32 MFMA)", c.precision);
     if ((c.pool_layers_mask & 1u) || (c.pool_layers_mask >> c.layers))
         return fail(nullptr, DAN_ERR_INVALID_ARG, "pool layers must lie in 1..layers-1");
     int ndev = 0;
@@ -255,6 +285,7 @@ int dan_finalize(dan_t* h) {
 
     // ---- conv stack: one fixed-stride weight block per layer (dan_kernels.h)
     std::vector<float> wl((size_t)c.layers * LAYER_STRIDE, 0.f);
+    std::vector<char> wl16(c.precision ? (size_t)c.layers * W16_LAYER_BYTES : 0, 0);
     std::vector<float> wc_all, bc_all((size_t)c.layers * HPAD, 0.f);
     const size_t wc_layer = (size_t)L * 2 * 2 * 64 * 4;      // [g = 2L][tile 2][lane 64][4]
     if (H > 0) wc_all.resize((size_t)c.layers * wc_layer);
@@ -283,6 +314,11 @@ int dan_finalize(dan_t* h) {
         };
         std::vector<float> packed = pack_frag(3, kg, KGC, Wf);
         std::copy(packed.begin(), packed.end(), blk + W_OFF);
+        char* blk16 = c.precision ? wl16.data() + (size_t)l * W16_LAYER_BYTES : nullptr;
+        if (blk16) {
+            auto Wf16 = [&](int o, int cc, int t) -> float { return Wf(o, cc, t); };   // channels beyond kg*16 read as 0
+            pack_frag16((uint16_t*)(blk16 + W16_CONV_OFF), W16_CONV_FRAGS, 3, l == 0 ? KG16_0 : KG16_C, KGC, Wf16);
+        }
         float* cst = blk + CST_OFF;
         for (int o = 0; o < cout; ++o) { cst[CST_BIAS + o] = b->data[o]; cst[CST_SCALE + o] = 1.f; }
         if (c.use_bn) {                                      // eval-mode BN after the ReLU, eps 1e-5 (model.py:750-751)
@@ -304,6 +340,7 @@ int dan_finalize(dan_t* h) {
             auto Wr = [&](int o, int cc, int) -> float { return (o < cout && cc < cout) ? wr->data[(size_t)o * cout + cc] : 0.f; };
             std::vector<float> pr = pack_frag(1, KGC, KGC, Wr);
             std::copy(pr.begin(), pr.end(), blk + WRES_OFF);
+            if (blk16) pack_frag16((uint16_t*)(blk16 + W16_RES_OFF), W16_RES_FRAGS, 1, KG16_C, KGC, Wr);
             for (int o = 0; o < cout; ++o) cst[CST_BRES + o] = br->data[o];
             h->res_mask |= 1u << l;
         }
@@ -314,6 +351,7 @@ int dan_finalize(dan_t* h) {
             auto Wb = [&](int o, int cc, int) -> float { return (o < H && cc < cout) ? wb->data[(size_t)o * cout + cc] : 0.f; };
             std::vector<float> pb = pack_frag(1, KGC, 2, Wb);
             std::copy(pb.begin(), pb.end(), blk + WBOT_OFF);
+            if (blk16) pack_frag16((uint16_t*)(blk16 + W16_BOT_OFF), W16_BOT_FRAGS, 1, KG16_C, 2, Wb);
             for (int o = 0; o < H; ++o) cst[CST_BBOT + o] = bb->data[o];
             const std::string z = "conv1D_compression_layers." + std::to_string(l);
             const Tensor* wcm = need(h, z + ".weight", {H, H, 1, L}, &rc); if (!wcm) return rc;
@@ -330,6 +368,12 @@ int dan_finalize(dan_t* h) {
                         }
             for (int o = 0; o < H; ++o) bc_all[(size_t)l * HPAD + o] = bcm->data[o];
         }
+    }
+    if (c.precision) {                                       // constants are shared: copy each layer's fp32 block tail
+        for (int l = 0; l < c.layers; ++l)
+            memcpy(wl16.data() + (size_t)l * W16_LAYER_BYTES + W16_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
+                   CST_FLOATS * sizeof(float));
+        if ((rc = dev_upload(h, &h->d_wl16, wl16))) return rc;
     }
     if ((rc = dev_upload(h, &h->d_wl, wl))) return rc;
     if (H > 0) {
@@ -428,7 +472,17 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 a.tap_layer = h->tap_layer;
                 EventPair ev{};
                 int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;
-                launch_segment(a, ns, s);
+                if (c.precision == 0) {
+                    launch_segment(a, ns, s);
+                } else {
+                    Segment16Args b{};
+                    b.wl = h->d_wl16; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
+                    b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
+                    b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
+                    b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe; b.y = a.y; b.pool = a.pool;
+                    b.h = a.h; b.h_layer_stride = a.h_layer_stride; b.tap = a.tap; b.tap_layer = a.tap_layer;
+                    launch_segment16(b, ns, c.precision, s);
+                }
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;

@@ -59,6 +59,39 @@ struct SegmentArgs {
 };
 
 void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s);
+
+// ---- bf16-MFMA family (dan_kernels_bf16.hip): precision 1 = bf16x3 (hi+lo split, L <= 208), 2 = bf16 (L <= 304)
+constexpr int S16 = 144;                 // bf16 elements per LDS position row (256 B + 32 B: conflict-free b128 reads)
+constexpr int KG16_0 = 2;                // 32-channel k-groups of layer 1 (48 encoded channels padded to 64)
+constexpr int KG16_C = CPAD / 32;        // 4
+constexpr int MT_MAX16 = 19;             // position tiles of the plain-bf16 instantiation (L <= 304)
+// per-layer weight block (bytes): every matrix as MFMA A fragments [step][tile][lane 64][8 bf16], hi plane then lo
+constexpr int W16_CONV_FRAGS = 3 * KG16_C * KGC * 64;            // fragments (16 B each) per plane
+constexpr int W16_RES_FRAGS = KG16_C * KGC * 64;
+constexpr int W16_BOT_FRAGS = KG16_C * 2 * 64;
+constexpr int W16_CONV_OFF = 0;
+constexpr int W16_RES_OFF = W16_CONV_OFF + 2 * W16_CONV_FRAGS * 16;
+constexpr int W16_BOT_OFF = W16_RES_OFF + 2 * W16_RES_FRAGS * 16;
+constexpr int W16_CST_OFF = W16_BOT_OFF + 2 * W16_BOT_FRAGS * 16;
+constexpr int W16_LAYER_BYTES = W16_CST_OFF + (CST_FLOATS + 32) * 4;
+
+struct Segment16Args {
+    const char* wl;              // [layers][W16_LAYER_BYTES]
+    int l_begin, l_end, n_layers, dil_mid, dil_final;
+    unsigned res_mask;
+    int has_hw;
+    int R, L;
+    const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
+    const float* emb;
+    const float* pe;
+    float* y;
+    const float* pool;
+    float* h;
+    long long h_layer_stride;
+    float* tap;
+    int tap_layer;
+};
+void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s);
 // pool[site][p][c] = mean over reads of y[site][r][p][c]          (dl4vc/model.py:772)
 void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, hipStream_t s);
 // feat[site][c*L+p] = max_r y, feat[site][C*L + c*L+p] = mean_r y   (dl4vc/model.py:824-839)

@@ -1,0 +1,361 @@
+// bf16-MFMA family of the conv-stack segment kernel for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+//   SPLIT = true  ("bf16x3", dan_config.precision = 1): every fp32 operand is carried as hi + lo bf16 and a
+//       product is three MFMAs  wh*xh + wl*xh + wh*xl  -- ~16 mantissa bits per operand, fp32 sums; softmax
+//       scores stay within 1e-4 of the fp32 reference (tests) at ~1/3 of the bf16 matrix rate, i.e. ~5x the
+//       fp32-MFMA rate.
+//   SPLIT = false ("bf16", precision = 2): plain bf16 operands; BASELINE config 5 (128 reads x 301 bp): the
+//       read still fits one CU's LDS (312 rows x 288 B), MT = 19 position tiles.
+//
+// Same structure as the fp32 kernel (dan_kernels.hip): one workgroup = one read resident in LDS for a whole
+// segment of layers, each wave owns 32 output channels x all position tiles, weights stream from L2 in MFMA
+// A-fragment order, B fragments are single-buffered ds_read_b128 (8 consecutive channels of one position)
+// re-filled right after their last use.  HBM formats are unchanged (fp32 y / pool / h), so the pooling,
+// highway and FC kernels are shared with the fp32 path.
+#include "dan_kernels.h"
+
+namespace dan {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) bf8* gbf8_ptr;
+
+__device__ __forceinline__ v4f mfma_bf16(bf8 a, bf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f splat4(float x) { return (v4f){x, x, x, x}; }
+__device__ __forceinline__ float relu1f(float v) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
+
+template <bool SPLIT, int MT>
+struct Geo {
+    static constexpr int MPOS_ = MT * 16;
+    static constexpr int ROWS = MPOS_ + 2 * HALO;
+    static constexpr int PLANE = ROWS * S16;                 // bf16 elements per plane
+    static constexpr int PLANES = SPLIT ? 2 : 1;
+    static constexpr int NP = SPLIT ? 2 : 1;                 // fragments per operand (hi [, lo])
+};
+
+// fp32 quad -> bf16 hi (+ lo) stored at one LDS cell (4 consecutive channels of one position)
+template <bool SPLIT, int PLANE>
+__device__ __forceinline__ void store_cell(__bf16* cell, v4f v) {
+    bf4 hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hi[j] = (__bf16)v[j];
+    *(bf4*)cell = hi;
+    if (SPLIT) {
+        bf4 lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        *(bf4*)(cell + PLANE) = lo;
+    }
+}
+
+template <bool SPLIT, int PLANE>
+__device__ __forceinline__ v4f load_cell(const __bf16* cell) {
+    const bf4 hi = *(const bf4*)cell;
+    v4f v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)hi[j];
+    if (SPLIT) {
+        const bf4 lo = *(const bf4*)(cell + PLANE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)lo[j];
+    }
+    return v;
+}
+
+// implicit GEMM over taps x 32-channel k-groups.  wl points at this wave's first hi fragment; the lo plane of the
+// same block lies lo_off fragments further.  Fragment index of (step, tile n): step*(tiles*64) + n*64.
+template <bool SPLIT, int MT, int TILES>
+__device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT], const __bf16* xs, gbf8_ptr wl, int lo_off,
+                                       const bf8 (&a_first)[NT][2], int kg, int ntaps, int dil, int lane) {
+    typedef Geo<SPLIT, MT> G;
+    const int pos = lane & 15, kq = lane >> 4;
+    const int total = ntaps * kg;
+    const int t0 = (ntaps == 3) ? -dil : 0;
+    const __bf16* xrow = xs + (HALO + pos) * S16 + kq * 8;
+    bf8 a_nxt[NT][2], bh[MT], bl[SPLIT ? MT : 1];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { a_nxt[n][0] = a_first[n][0]; a_nxt[n][1] = a_first[n][1]; }
+    {
+        const __bf16* xb = xrow + t0 * S16;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bh[m] = *(const bf8*)(xb + m * 16 * S16);
+            if (SPLIT) bl[m] = *(const bf8*)(xb + m * 16 * S16 + G::PLANE);
+        }
+    }
+    int t = 0, g = 0;
+    for (int it = 0; it < total; ++it) {
+        bf8 a[NT][2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { a[n][0] = a_nxt[n][0]; a[n][1] = a_nxt[n][1]; }
+        const int nx = (it + 1 < total) ? it + 1 : it;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            a_nxt[n][0] = wl[(size_t)nx * (TILES * 64) + n * 64];
+            if (SPLIT) a_nxt[n][1] = wl[(size_t)nx * (TILES * 64) + n * 64 + lo_off];
+        }
+        int tn = t, gn = g + 1;
+        if (gn == kg) { gn = 0; ++tn; }
+        if (it + 1 == total) { tn = t; gn = g; }
+        const __bf16* xn = xrow + (t0 + tn * dil) * S16 + gn * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(a[n][0], bh[m], acc[m][n]);
+            if (SPLIT) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(a[n][1], bh[m], acc[m][n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(a[n][0], bl[m], acc[m][n]);
+            }
+            bh[m] = *(const bf8*)(xn + m * 16 * S16);
+            if (SPLIT) bl[m] = *(const bf8*)(xn + m * 16 * S16 + G::PLANE);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, NT * G::NP, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NT * (SPLIT ? 3 : 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, G::NP, 0);
+        }
+        t = tn; g = gn;
+    }
+}
+
+// 128 -> 32 highway bottleneck.  Unit u = 2*pt + n is owned by wave u & 3: every wave has a fixed channel
+// tile n = wave & 1 and the position tiles of parity wave >> 1 (7/7/6/6 units at MT = 13, 10/10/9/9 at 19).
+template <bool SPLIT, int MT>
+__device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int lo_off, const float* bbot, float* hrow,
+                                             int L, int wave, int lane) {
+    typedef Geo<SPLIT, MT> G;
+    constexpr int NB = (MT + 1) / 2;
+    constexpr int KG = CPAD / 32;
+    const int pos = lane & 15, kq = lane >> 4;
+    const int n = wave & 1, p0 = wave >> 1;
+    const __bf16* xrow = xs + (HALO + pos) * S16 + kq * 8;
+    bf8 ah[KG], al[SPLIT ? KG : 1];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        ah[g] = wb[(g * 2 + n) * 64];
+        if (SPLIT) al[g] = wb[(g * 2 + n) * 64 + lo_off];
+    }
+    v4f acc[NB];
+    {
+        const v4f b = *(const v4f*)(bbot + n * 16 + kq * 4);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = b;
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int pt = min(p0 + 2 * i, MT - 1);
+            const bf8 bh = *(const bf8*)(xrow + pt * 16 * S16 + g * 32);
+            acc[i] = mfma_bf16(ah[g], bh, acc[i]);
+            if (SPLIT) {
+                const bf8 bl = *(const bf8*)(xrow + pt * 16 * S16 + g * 32 + G::PLANE);
+                acc[i] = mfma_bf16(al[g], bh, acc[i]);
+                acc[i] = mfma_bf16(ah[g], bl, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pt = p0 + 2 * i, p = pt * 16 + pos;
+        if (pt < MT && p < L) {
+            v4f v = acc[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = relu1f(v[j]);
+            *(v4f*)(hrow + (size_t)p * HPAD + n * 16 + kq * 4) = v;
+        }
+    }
+}
+
+template <bool SPLIT, int MT>
+__device__ __forceinline__ void copy_out16(const __bf16* xs, float* dst, int L, int tid) {
+    for (int i = tid; i < L * (CPAD / 4); i += 256) {
+        const int p = i >> 5, c4 = i & 31;
+        ((v4f*)dst)[i] = load_cell<SPLIT, Geo<SPLIT, MT>::PLANE>(xs + (HALO + p) * S16 + c4 * 4);
+    }
+}
+
+template <bool SPLIT, int MT>
+__global__ __launch_bounds__(256, 1) void segment16_kernel(Segment16Args a) {
+    typedef Geo<SPLIT, MT> G;
+    __shared__ __attribute__((aligned(16))) __bf16 xs[G::PLANES * G::PLANE];
+    __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int site = blockIdx.x / a.R, r = blockIdx.x - site * a.R;
+    const int L = a.L;
+    const size_t read_idx = (size_t)site * a.R + r;
+    float* yrow = a.y + read_idx * (size_t)L * CPAD;
+    const int pos = lane & 15, kq = lane >> 4;
+    int chb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kq * 4;
+
+    auto block = [&](int l) { return a.wl + (size_t)l * W16_LAYER_BYTES; };
+    auto conv_ptr = [&](int l) { return (gbf8_ptr)(block(l) + W16_CONV_OFF) + (wave * NT) * 64 + lane; };
+    bf8 pre_conv[NT][2];
+    {
+        gbf8_ptr w0 = conv_ptr(a.l_begin);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { pre_conv[n][0] = w0[n * 64]; pre_conv[n][1] = w0[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)]; }
+    }
+    for (int i = tid; i < G::PLANES * G::PLANE / 8; i += 256) ((v4f*)xs)[i] = splat4(0.f);
+    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += 256) {
+        const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
+        cst[i] = *(const float*)(block(a.l_begin + l) + W16_CST_OFF + (size_t)j * 4);
+    }
+    __syncthreads();
+
+    if (a.l_begin == 0) {
+        // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, rounded to bf16 (hi [+ lo])
+        const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+        int ok_ref = 1, ok_var = 1;
+        for (int p = tid; p < L; p += 256) {
+            const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+            ok_ref &= (rm == 0) || (tok == rm);
+            ok_var &= (vm == 0) || (tok == vm);
+        }
+        const int agree_ref = __syncthreads_and(ok_ref);
+        const int agree_var = __syncthreads_and(ok_var);
+        for (int p = tid; p < L; p += 256) {
+            const int tok = a.reads[rbase + p], q = a.qual[rbase + p], st = a.strand[rbase + p];
+            const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+            const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
+            const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
+            const float* pp = a.pe + p * EMBED;
+            float row[CIN0];
+#pragma unroll
+            for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
+            row[40] = (float)q * 0.01f;
+            row[41] = (float)st * 0.5f;
+            row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
+            row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
+            row[44] = (rm != 0) ? 1.f : 0.f;
+            row[45] = row[46] = row[47] = 0.f;
+            __bf16* cell = xs + (HALO + p) * S16;
+#pragma unroll
+            for (int c = 0; c < CIN0; c += 4) store_cell<SPLIT, G::PLANE>(cell + c, (v4f){row[c], row[c + 1], row[c + 2], row[c + 3]});
+        }
+    } else {
+        const v4f* src = (const v4f*)yrow;
+        const v4f* pl = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
+        const int n4 = L * (CPAD / 4);
+#pragma unroll 4
+        for (int i = tid; i < n4; i += 256) {
+            v4f v = src[i];
+            if (pl) v += pl[i];
+            store_cell<SPLIT, G::PLANE>(xs + (HALO + (i >> 5)) * S16 + (i & 31) * 4, v);
+        }
+    }
+    __syncthreads();
+    if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out16<SPLIT, MT>(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+
+    for (int l = a.l_begin; l < a.l_end; ++l) {
+        const float* lc = cst + (l - a.l_begin) * CST_FLOATS;
+        const bool residual = (a.res_mask >> l) & 1u;
+        const int kg = (l == 0) ? KG16_0 : KG16_C;
+        const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
+        gbf8_ptr w_conv = conv_ptr(l);
+        gbf8_ptr w_res = (gbf8_ptr)(block(l) + W16_RES_OFF) + (wave * NT) * 64 + lane;
+        gbf8_ptr w_bot = (gbf8_ptr)(block(l) + W16_BOT_OFF) + lane;
+        bf8 pre_res[NT][2], pre_next[NT][2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            pre_res[n][0] = w_res[n * 64];
+            pre_res[n][1] = w_res[n * 64 + (SPLIT ? W16_RES_FRAGS : 0)];
+            gbf8_ptr wn = (l + 1 < a.l_end) ? conv_ptr(l + 1) : w_conv;
+            pre_next[n][0] = wn[n * 64];
+            pre_next[n][1] = wn[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)];
+        }
+
+        v4f acc[MT][NT];
+        {
+            v4f bias[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bias[n] = *(const v4f*)(lc + CST_BIAS + chb[n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
+        }
+        gemm16<SPLIT, MT, KGC>(acc, xs, w_conv, W16_CONV_FRAGS, pre_conv, kg, 3, dil, lane);
+        {
+            v4f sc[NT], sh[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { sc[n] = *(const v4f*)(lc + CST_SCALE + chb[n]); sh[n] = *(const v4f*)(lc + CST_SHIFT + chb[n]); }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    v4f v = acc[m][n];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = relu1f(v[j]) * sc[n][j] + sh[n][j];
+                    acc[m][n] = v;
+                }
+                if ((m + 1) * 16 > L) {
+                    const bool live = (m * 16 + pos) < L;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat4(0.f);
+                }
+            }
+        }
+        __syncthreads();
+        if (residual) {
+            v4f bres[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bres[n] = *(const v4f*)(lc + CST_BRES + chb[n]);
+            const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int p = m * 16 + pos;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    __bf16* cell = xs + (HALO + p) * S16 + chb[n];
+                    v4f old = load_cell<SPLIT, G::PLANE>(cell);
+                    if (from_global) old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat4(0.f);
+                    store_cell<SPLIT, G::PLANE>(cell, acc[m][n]);
+                    acc[m][n] = old + bres[n];
+                }
+            }
+            __syncthreads();
+            gemm16<SPLIT, MT, KGC>(acc, xs, w_res, W16_RES_FRAGS, pre_res, KG16_C, 1, 0, lane);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if ((m + 1) * 16 > L) {
+                    const bool live = (m * 16 + pos) < L;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat4(0.f);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
+        }
+        __syncthreads();
+        if (a.tap && a.tap_layer == l + 1) copy_out16<SPLIT, MT>(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+        if (a.has_hw)
+            bottleneck16<SPLIT, MT>(xs, w_bot, W16_BOT_FRAGS, lc + CST_BBOT,
+                                    a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { pre_conv[n][0] = pre_next[n][0]; pre_conv[n][1] = pre_next[n][1]; }
+    }
+    copy_out16<SPLIT, MT>(xs, yrow, L, tid);
+}
+
+void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s) {
+    const dim3 grid((unsigned)(n_sites * a.R)), blk(256);
+    if (precision == 1) hipLaunchKernelGGL((segment16_kernel<true, 13>), grid, blk, 0, s, a);
+    else if (a.L <= 13 * 16) hipLaunchKernelGGL((segment16_kernel<false, 13>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((segment16_kernel<false, 19>), grid, blk, 0, s, a);
+}
+
+}  // namespace dan

@@ -1,0 +1,77 @@
+"""bf16-MFMA family of the conv-stack kernel (dan_config.precision 1 = bf16x3 split, 2 = plain bf16).  GPU only.
+
+Tolerances (north_star: scores within 1e-4 of the fp32 reference):
+  * bf16x3 carries every operand as hi+lo bf16 (~16 mantissa bits) with fp32 accumulation: scores are held to the
+    same 1e-4 absolute bar as the fp32 path (observed 1e-6 .. 5e-5); logits/taps to 1e-4 of the tensor's magnitude x 4.
+  * plain bf16 (BASELINE config 5, 128 reads x 301 bp) has 8 mantissa bits: logits are held to 3 % of their
+    magnitude and probabilities to 0.05 -- this mode is a stress/throughput configuration, not a parity path."""
+import numpy as np
+import pytest
+
+from golden_util import load_case, input_tuple
+from dl4vc_amd.config import DanConfig, PRECISION_BF16X3, PRECISION_BF16
+from dl4vc_amd.model import DanNet
+from dl4vc_amd import synth
+from oracle.dan_oracle import dan_forward_oracle, random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(spec, precision):
+    keys = DanConfig.__dataclass_fields__.keys()
+    d = {k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in keys}
+    d["precision"] = precision
+    return DanConfig(**d)
+
+
+@pytest.mark.parametrize("case", ["dan_small", "dan_var_pool24", "dan_var_l5res2", "dan_var_cfinal", "dan_var_nohw"])
+def test_bf16x3_golden_scores(case):
+    spec, w, inp, out = load_case(case)
+    net = DanNet(_cfg(spec, PRECISION_BF16X3)).load_state_dict(w)
+    got = net.forward_u8(*input_tuple(inp))
+    net.close()
+    assert np.abs(got["vt_prob"] - out["vt_prob"]).max() < 1e-4
+    assert np.abs(got["bp"] - out["bp"]).max() < 1e-4
+    scale = max(1.0, float(np.abs(out["vt_logits"]).max()))
+    assert np.abs(got["vt_logits"] - out["vt_logits"]).max() < 4e-4 * scale
+
+
+def test_bf16x3_production_shape():
+    cfg = DanConfig(reads=64, precision=PRECISION_BF16X3)
+    sd = random_state_dict(cfg, seed=7)
+    batch = synth.make_sites(6, reads=64, seed=134)
+    net = DanNet(cfg).load_state_dict(sd)
+    got = net.forward_u8(*batch.arrays())
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    err = float(np.abs(got["vt_prob"] - want["vt_prob"]).max())
+    print("bf16x3 max |vt_prob - oracle| = %.3g, |bp| = %.3g" % (err, np.abs(got["bp"] - want["bp"]).max()))
+    assert err < 1e-4 and np.abs(got["bp"] - want["bp"]).max() < 1e-4
+    # chunking leaves results bit-identical in this mode too
+    b = DanNet(cfg, chunk_sites=4, max_batch=4).load_state_dict(sd)
+    again = b.forward_u8(*batch.arrays())
+    np.testing.assert_array_equal(again["vt_prob"], got["vt_prob"])
+    net.close(); b.close()
+
+
+def test_bf16_config5_stress_shape():
+    """BASELINE config 5: 128 reads x 301 bp, bf16."""
+    cfg = DanConfig(reads=128, length=301, precision=PRECISION_BF16)
+    assert cfg.feature_width == 105728
+    sd = random_state_dict(cfg, seed=3)
+    batch = synth.make_sites(2, reads=128, length=301, seed=4)
+    net = DanNet(cfg).load_state_dict(sd)
+    got = net.forward_u8(*batch.arrays())
+    net.close()
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    assert np.isfinite(got["vt_logits"]).all()
+    scale = float(np.abs(want["vt_logits"]).max())
+    assert np.abs(got["vt_logits"] - want["vt_logits"]).max() < 0.03 * scale
+    assert np.abs(got["vt_prob"] - want["vt_prob"]).max() < 0.05
+
+
+def test_fp32_rejects_long_window_but_bf16_accepts():
+    with pytest.raises(RuntimeError, match="length"):
+        DanNet(DanConfig(reads=8, length=301))
+    with pytest.raises(RuntimeError, match="length"):
+        DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16X3))
+    DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16)).close()

@@ -15,14 +15,18 @@ from oracle.dan_oracle import dan_forward_oracle, random_state_dict   # noqa: E4
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
+    prec = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if which == "small":
-        cfg = DanConfig(reads=8, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8))
+        cfg = DanConfig(reads=8, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8), precision=prec)
     elif which == "mid":
-        cfg = DanConfig(reads=16, c_init=128, c_final=128, bottleneck=32, fc_sizes=(64, 32))
+        cfg = DanConfig(reads=16, c_init=128, c_final=128, bottleneck=32, fc_sizes=(64, 32), precision=prec)
+    elif which == "stress":
+        cfg = DanConfig(reads=128, length=301, precision=prec)
     else:
-        cfg = DanConfig(reads=64)
+        cfg = DanConfig(reads=64, precision=prec)
+    print("config", which, "precision", prec)
     sd = random_state_dict(cfg, seed=1)
-    batch = synth.make_sites(3, reads=cfg.reads, seed=2)
+    batch = synth.make_sites(3 if which != "stress" else 2, reads=cfg.reads, length=cfg.length, seed=2)
     want = dan_forward_oracle(sd, cfg, *batch.arrays(), taps=True)
     net = DanNet(cfg).load_state_dict(sd)
     B, R, L = batch.reads.shape
