@@ -242,7 +242,7 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         return fail(nullptr, DAN_ERR_NO_DEVICE, "no HIP device %d (found %d): the DAN forward has no CPU path", c.device_id, ndev);
     dan_handle* h = new dan_handle();
     h->cfg = c;
-    h->chunk = c.chunk_sites > 0 ? c.chunk_sites : 64;
+    h->chunk = c.chunk_sites > 0 ? c.chunk_sites : 128;
     h->max_batch = c.max_batch > 0 ? c.max_batch : 4096;
     h->max_batch = ((h->max_batch + h->chunk - 1) / h->chunk) * h->chunk;
     h->F = 2 * c.c_final * c.length + c.layers * c.bottleneck * c.reads;

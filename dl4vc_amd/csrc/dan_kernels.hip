@@ -105,69 +105,50 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, g
     }
 }
 
-// 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.  26 output
-// tiles (13 position tiles x 2 channel tiles): wave w owns position tiles {w, w+4, w+8} x both channel
-// tiles, and position tile 12 is split by channel tile between waves 0/1 (waves 2/3 shadow them so that
-// every wave runs the same seven-tile stream; only the owners store).
-__device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC][2], const float* bbot, float* hrow,
-                                           int L, int wave, int lane) {
+// 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.  Output unit
+// u = 2*pt + n (13 position tiles x 2 channel tiles) is owned by wave u & 3: every wave has ONE channel tile
+// n = wave & 1 (so one weight fragment per k-group, no selects) and the position tiles of parity wave >> 1
+// -- 7/7/6/6 units.  All eight weight fragments are preloaded by the caller (wf).
+constexpr int NBT = (MT + 1) / 2;
+__device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
+                                           int wave, int lane) {
     const int pos = lane & 15, kk = lane >> 4;
-    const bool odd = wave & 1;
+    const int n = wave & 1, p0 = wave >> 1;
     const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
-    v4f acc[3][2], acc7, b[4];
-    {
-        const v4f b0 = *(const v4f*)(bbot + kk * 4), b1 = *(const v4f*)(bbot + 16 + kk * 4);
+    int roff[NBT];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { acc[i][0] = b0; acc[i][1] = b1; }
-        acc7 = odd ? b1 : b0;
+    for (int i = 0; i < NBT; ++i) roff[i] = min(p0 + 2 * i, MT - 1) * 16 * LDS_S;
+    v4f acc[NBT], b[NBT];
+    {
+        const v4f bias = *(const v4f*)(bbot + n * 16 + kk * 4);
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) acc[i] = bias;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) b[i] = *(const v4f*)(xrow + (wave + 4 * i) * 16 * LDS_S);
-    b[3] = *(const v4f*)(xrow + 12 * 16 * LDS_S);
+    for (int i = 0; i < NBT; ++i) b[i] = *(const v4f*)(xrow + roff[i]);
 #pragma unroll
     for (int g = 0; g < KGC; ++g) {
         const int gn = (g + 1 < KGC) ? g + 1 : g;
-        const v4f a7 = odd ? wf[g][1] : wf[g][0];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NBT; ++i) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[i][0] = mfma16(wf[g][0][s], b[i][s], acc[i][0]);
-                acc[i][1] = mfma16(wf[g][1][s], b[i][s], acc[i][1]);
-            }
-            b[i] = *(const v4f*)(xrow + (wave + 4 * i) * 16 * LDS_S + gn * 16);
+            for (int s = 0; s < 4; ++s) acc[i] = mfma16(wf[g][s], b[i][s], acc[i]);
+            b[i] = *(const v4f*)(xrow + roff[i] + gn * 16);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc7 = mfma16(a7[s], b[3][s], acc7);
-        b[3] = *(const v4f*)(xrow + 12 * 16 * LDS_S + gn * 16);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        for (int i = 0; i < NBT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int p = (wave + 4 * i) * 16 + pos;
-        if (p < L) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                v4f v = acc[i][n];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
-                *(v4f*)(hrow + (size_t)p * HPAD + n * 16 + kk * 4) = v;
-            }
-        }
-    }
-    {
-        const int p = 12 * 16 + pos;
-        if (wave < 2 && p < L) {
-            v4f v = acc7;
+    for (int i = 0; i < NBT; ++i) {
+        const int pt = p0 + 2 * i, p = pt * 16 + pos;
+        if (pt < MT && p < L) {
+            v4f v = acc[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
-            *(v4f*)(hrow + (size_t)p * HPAD + wave * 16 + kk * 4) = v;
+            *(v4f*)(hrow + (size_t)p * HPAD + n * 16 + kk * 4) = v;
         }
     }
 }
@@ -310,12 +291,12 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
         STAMP(sb + 0);
         conv_gemm(acc, xs, w_conv, pre_conv, kg, 3, dil, lane);
         STAMP(sb + 1);
-        // all sixteen bottleneck weight fragments of this layer: issued now, consumed after the epilogue
+        // this wave's eight bottleneck weight fragments of the layer: issued now, consumed after the epilogue
         // (and the residual GEMM), so the ~1.5k-cycle loaded-L2 latency is off the critical path
-        v4f wbot[KGC][2];
+        v4f wbot[KGC];
         if (a.has_hw) {
 #pragma unroll
-            for (int g = 0; g < KGC; ++g) { wbot[g][0] = w_bot[(g * 2) * 64]; wbot[g][1] = w_bot[(g * 2 + 1) * 64]; }
+            for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
         }
         // ---- epilogue: ReLU then eval-mode BatchNorm as one affine (model.py:749-751); rows >= L stay zero
         {
