@@ -7,8 +7,9 @@ namespace dan {
 
 // ---- fixed geometry of the fp32 path -----------------------------------------------------------
 constexpr int CPAD = 128;               // channel capacity of one activation row (c_init, c_final <= 128)
-constexpr int NWAVE = 4;                // waves per workgroup, one per SIMD
-constexpr int NT = 2;                   // 16-channel output tiles per wave   (CPAD / 16 / NWAVE)
+constexpr int NWAVE = 8;                // waves per workgroup, two per SIMD: one covers the other's waits and epilogues
+constexpr int NT = 1;                   // 16-channel output tiles per wave   (CPAD / 16 / NWAVE)
+constexpr int SEG_THREADS = NWAVE * 64;
 constexpr int MT = 13;                  // 16-position tiles per read         (L <= 208)
 constexpr int MPOS = MT * 16;           // 208
 constexpr int HALO = 4;                 // zero rows either side of the window (dilation <= 4)

@@ -2,9 +2,9 @@
 //
 // Hot loop: every convolution of the stack is an implicit GEMM  D[out-channel][position] +=
 // W[out-channel][k] * X[k][position]  on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  One
-// workgroup (4 waves, one per SIMD) owns ONE READ: its 201 x 128 activation lives in LDS for the
-// whole segment of layers (position-major rows of 132 floats, zero halo rows either side), each wave
-// owns 32 output channels x all 13 position tiles (104 accumulator registers), weights stream from
+// workgroup (8 waves, two per SIMD) owns ONE READ: its 201 x 128 activation lives in LDS for the
+// whole segment of layers (position-major rows of 136 floats, zero halo rows either side), each wave
+// owns 16 output channels x all 13 position tiles (52 accumulator registers), weights stream from
 // L2 straight into A fragments (host-packed in fragment order, 1 KiB coalesced per wave-load), the
 // activation B fragments come from LDS as ds_read_b128 (the K order inside a 16-channel group is
 // permuted so that one 16-byte read feeds four MFMA k-steps).  ReLU, folded BatchNorm, the 1x1
@@ -98,7 +98,7 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, g
         __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);         // the weight loads first
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // 8 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);  // one tile's MFMAs
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
         }
         t = tn; g = gn;
@@ -106,10 +106,11 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, g
 }
 
 // 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.  Output unit
-// u = 2*pt + n (13 position tiles x 2 channel tiles) is owned by wave u & 3: every wave has ONE channel tile
-// n = wave & 1 (so one weight fragment per k-group, no selects) and the position tiles of parity wave >> 1
-// -- 7/7/6/6 units.  All eight weight fragments are preloaded by the caller (wf).
-constexpr int NBT = (MT + 1) / 2;
+// u = 2*pt + n (13 position tiles x 2 channel tiles) is owned by wave u % NWAVE: every wave has ONE channel tile
+// n = wave & 1 (so one weight fragment per k-group, no selects) and the position tiles pt = (wave >> 1) mod 4
+// -- 4/4/3/3/3/3/3/3 units, i.e. 7/7/6/6 per SIMD.  All eight weight fragments are preloaded by the caller (wf).
+constexpr int PSTEP = NWAVE / 2;                      // position-tile stride of one wave
+constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
 __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
                                            int wave, int lane) {
     const int pos = lane & 15, kk = lane >> 4;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
     const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
     int roff[NBT];
 #pragma unroll
-    for (int i = 0; i < NBT; ++i) roff[i] = min(p0 + 2 * i, MT - 1) * 16 * LDS_S;
+    for (int i = 0; i < NBT; ++i) roff[i] = min(p0 + PSTEP * i, MT - 1) * 16 * LDS_S;
     v4f acc[NBT], b[NBT];
     {
         const v4f bias = *(const v4f*)(bbot + n * 16 + kk * 4);
@@ -143,7 +144,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
     }
 #pragma unroll
     for (int i = 0; i < NBT; ++i) {
-        const int pt = p0 + 2 * i, p = pt * 16 + pos;
+        const int pt = p0 + PSTEP * i, p = pt * 16 + pos;
         if (pt < MT && p < L) {
             v4f v = acc[i];
 #pragma unroll
@@ -154,7 +155,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
 }
 
 __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int tid) {
-    for (int i = tid; i < L * (CPAD / 4); i += 256) {
+    for (int i = tid; i < L * (CPAD / 4); i += SEG_THREADS) {
         const int p = i >> 5, c4 = i & 31;
         ((v4f*)dst)[i] = *(const v4f*)(xs + (HALO + p) * LDS_S + c4 * 4);
     }
@@ -163,7 +164,7 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
 // ------------------------------------------------------------------------------------------------
 // segment kernel: one workgroup = one read, layers [l_begin, l_end) with the read resident in LDS
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
     __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
     const int tid = threadIdx.x;
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) pre_conv[n] = w0[n * 64];
     }
-    for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += 256) ((v4f*)xs)[i] = splat(0.f);
-    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += 256) {
+    for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
         const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
         cst[i] = a.wl[(size_t)(a.l_begin + l) * LAYER_STRIDE + CST_OFF + j];
     }
@@ -232,17 +233,17 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
         // a single CU streams at (bytes in flight) / latency: put the whole read (and the pool image) in flight
         // at once -- 26 + 26 sixteen-byte loads per lane -- instead of a few loads per round trip
         const int n4 = L * (CPAD / 4);
-        constexpr int NP = MPOS * (CPAD / 4) / 256;          // 26
+        constexpr int NP = MPOS * (CPAD / 4) / SEG_THREADS;
         v4f vy[NP], vp[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int i = tid + k * 256;
+            const int i = tid + k * SEG_THREADS;
             vy[k] = (i < n4) ? src[i] : splat(0.f);
         }
         if (pl) {
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                const int i = tid + k * 256;
+                const int i = tid + k * SEG_THREADS;
                 vp[k] = (i < n4) ? pl[i] : splat(0.f);
             }
         } else {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int i = tid + k * 256;
+            const int i = tid + k * SEG_THREADS;
             if (i < n4) *(v4f*)(xs + (HALO + (i >> 5)) * LDS_S + (i & 31) * 4) = vy[k] + vp[k];
         }
     }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void segment_kernel(SegmentArgs a) {
 }
 
 void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s) {
-    hipLaunchKernelGGL(segment_kernel, dim3((unsigned)(n_sites * a.R)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(segment_kernel, dim3((unsigned)(n_sites * a.R)), dim3(SEG_THREADS), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
