@@ -55,11 +55,10 @@ constexpr int NSTAMP = 64;
 // weight fragments are loaded by the caller well ahead of the call (a_first).
 typedef const __attribute__((address_space(1))) v4f* gv4f_ptr;     // global (not flat) loads
 
-__device__ __forceinline__ float relu1(float v) {                  // one v_max_f32 (fmaxf costs two)
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
+// ReLU as ONE compiler-visible instruction (v_med3_f32 v, 0, +inf).  Not inline asm: an asm block that reads an
+// MFMA result is invisible to hipcc's hazard recognizer (no wait states are inserted between the MFMA and the asm),
+// and fmaxf costs two instructions (canonicalise + max).
+__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 
 __device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, gv4f_ptr wl, const v4f (&a_first)[NT],
                                           int kg, int ntaps, int dil, int lane) {

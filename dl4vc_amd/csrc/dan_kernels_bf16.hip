@@ -23,7 +23,8 @@ typedef const __attribute__((address_space(1))) bf8* gbf8_ptr;
 
 __device__ __forceinline__ v4f mfma_bf16(bf8 a, bf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ v4f splat4(float x) { return (v4f){x, x, x, x}; }
-__device__ __forceinline__ float relu1f(float v) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
+// one compiler-visible instruction (an inline-asm v_max reading an MFMA result gets no hazard wait states)
+__device__ __forceinline__ float relu1f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 
 template <bool SPLIT, int MT>
 struct Geo {
@@ -122,13 +123,14 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT], const __bf16* xs, gbf
     }
 }
 
-// 128 -> 32 highway bottleneck.  Unit u = 2*pt + n is owned by wave u & 3: every wave has a fixed channel
-// tile n = wave & 1 and the position tiles of parity wave >> 1 (7/7/6/6 units at MT = 13, 10/10/9/9 at 19).
+// 128 -> 32 highway bottleneck.  Unit u = 2*pt + n is owned by wave u % NWAVE: every wave has a fixed channel
+// tile n = wave & 1 and the position tiles pt = (wave >> 1) mod (NWAVE/2).
 template <bool SPLIT, int MT>
 __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int lo_off, const float* bbot, float* hrow,
                                              int L, int wave, int lane) {
     typedef Geo<SPLIT, MT> G;
-    constexpr int NB = (MT + 1) / 2;
+    constexpr int PS = NWAVE / 2;
+    constexpr int NB = (MT + PS - 1) / PS;
     constexpr int KG = CPAD / 32;
     const int pos = lane & 15, kq = lane >> 4;
     const int n = wave & 1, p0 = wave >> 1;
@@ -149,7 +151,7 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int 
     for (int g = 0; g < KG; ++g) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int pt = min(p0 + 2 * i, MT - 1);
+            const int pt = min(p0 + PS * i, MT - 1);
             const bf8 bh = *(const bf8*)(xrow + pt * 16 * S16 + g * 32);
             acc[i] = mfma_bf16(ah[g], bh, acc[i]);
             if (SPLIT) {
@@ -161,7 +163,7 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int 
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int pt = p0 + 2 * i, p = pt * 16 + pos;
+        const int pt = p0 + PS * i, p = pt * 16 + pos;
         if (pt < MT && p < L) {
             v4f v = acc[i];
 #pragma unroll
@@ -173,14 +175,14 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int 
 
 template <bool SPLIT, int MT>
 __device__ __forceinline__ void copy_out16(const __bf16* xs, float* dst, int L, int tid) {
-    for (int i = tid; i < L * (CPAD / 4); i += 256) {
+    for (int i = tid; i < L * (CPAD / 4); i += SEG_THREADS) {
         const int p = i >> 5, c4 = i & 31;
         ((v4f*)dst)[i] = load_cell<SPLIT, Geo<SPLIT, MT>::PLANE>(xs + (HALO + p) * S16 + c4 * 4);
     }
 }
 
 template <bool SPLIT, int MT>
-__global__ __launch_bounds__(256, 1) void segment16_kernel(Segment16Args a) {
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segment16Args a) {
     typedef Geo<SPLIT, MT> G;
     __shared__ __attribute__((aligned(16))) __bf16 xs[G::PLANES * G::PLANE];
     __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(256, 1) void segment16_kernel(Segment16Args a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) { pre_conv[n][0] = w0[n * 64]; pre_conv[n][1] = w0[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)]; }
     }
-    for (int i = tid; i < G::PLANES * G::PLANE / 8; i += 256) ((v4f*)xs)[i] = splat4(0.f);
-    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += 256) {
+    for (int i = tid; i < G::PLANES * G::PLANE / 8; i += SEG_THREADS) ((v4f*)xs)[i] = splat4(0.f);
+    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
         const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
         cst[i] = *(const float*)(block(a.l_begin + l) + W16_CST_OFF + (size_t)j * 4);
     }
@@ -214,14 +216,14 @@ __global__ __launch_bounds__(256, 1) void segment16_kernel(Segment16Args a) {
         // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, rounded to bf16 (hi [+ lo])
         const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
         int ok_ref = 1, ok_var = 1;
-        for (int p = tid; p < L; p += 256) {
+        for (int p = tid; p < L; p += SEG_THREADS) {
             const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
             ok_ref &= (rm == 0) || (tok == rm);
             ok_var &= (vm == 0) || (tok == vm);
         }
         const int agree_ref = __syncthreads_and(ok_ref);
         const int agree_var = __syncthreads_and(ok_var);
-        for (int p = tid; p < L; p += 256) {
+        for (int p = tid; p < L; p += SEG_THREADS) {
             const int tok = a.reads[rbase + p], q = a.qual[rbase + p], st = a.strand[rbase + p];
             const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
             const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void segment16_kernel(Segment16Args a) {
         const v4f* pl = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
         const int n4 = L * (CPAD / 4);
 #pragma unroll 4
-        for (int i = tid; i < n4; i += 256) {
+        for (int i = tid; i < n4; i += SEG_THREADS) {
             v4f v = src[i];
             if (pl) v += pl[i];
             store_cell<SPLIT, G::PLANE>(xs + (HALO + (i >> 5)) * S16 + (i & 31) * 4, v);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void segment16_kernel(Segment16Args a) {
 }
 
 void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s) {
-    const dim3 grid((unsigned)(n_sites * a.R)), blk(256);
+    const dim3 grid((unsigned)(n_sites * a.R)), blk(SEG_THREADS);
     if (precision == 1) hipLaunchKernelGGL((segment16_kernel<true, 13>), grid, blk, 0, s, a);
     else if (a.L <= 13 * 16) hipLaunchKernelGGL((segment16_kernel<false, 13>), grid, blk, 0, s, a);
     else hipLaunchKernelGGL((segment16_kernel<false, 19>), grid, blk, 0, s, a);
