@@ -66,6 +66,8 @@ _EXTRA = [
                                "it from an unseeded RNG, dl4vc/dataset.py:274-281)"),
     ("--sites-per-launch", "int", 4096, "candidate sites per device launch (FC macro-batch)"),
     ("--shard", "str", "", "i/n: process only the i-th of n contiguous site shards (multi-GPU launch sets this)"),
+    ("--precision", "str", "fp32", "conv-stack arithmetic: fp32 (exact fp32 MFMA, default), bf16x3 (split bf16, scores "
+                                   "within 1e-4, ~2.3x faster) or bf16"),
 ]
 
 _TYPES = {"int": int, "float": float, "str": str}

@@ -36,6 +36,11 @@ def main(argv=None) -> int:
     from dl4vc_amd.vcf import scored_vcf_path, start_scored_vcf
 
     cfg = DanConfig.from_args(args)                           # rejects unsupported model options loudly
+    if args.precision not in ("fp32", "bf16x3", "bf16"):
+        raise SystemExit("--precision must be fp32, bf16x3 or bf16")
+    if args.precision != "fp32":
+        import dataclasses
+        cfg = dataclasses.replace(cfg, precision=("fp32", "bf16x3", "bf16").index(args.precision))
     shard_i, shard_n = parse_shard(args.shard)
     if args.save_vcf_records:
         assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"
