@@ -293,8 +293,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         STAMP(sb + 1);
         // this wave's eight bottleneck weight fragments of the layer: issued now, consumed after the epilogue
         // (and the residual GEMM), so the ~1.5k-cycle loaded-L2 latency is off the critical path
+        // (for residual layers they are issued after the residual GEMM instead, to keep 32 registers free in it)
         v4f wbot[KGC];
-        if (a.has_hw) {
+        if (a.has_hw && !residual) {
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
         }
@@ -355,6 +356,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             STAMP(sb + 4);
             conv_gemm(acc, xs, w_res, pre_res, KGC, 1, 0, lane);
             STAMP(sb + 5);
+            if (a.has_hw) {
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
+            }
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
