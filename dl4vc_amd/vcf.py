@@ -65,6 +65,26 @@ def append_scored_records(vcf_file: str, bp: Iterable[float], vt: Iterable[Seque
         f.write("".join(scored_record(r, b, v) + "\n" for r, b, v in zip(vcf_records, bp, vt)))
 
 
+def sort_scored_vcf_lines(lines: Sequence[str]) -> List[str]:
+    """In-process twin of the pipeline's sort stage (call_variants.sh:151):
+    ``awk '$1 ~ /^#/ {print; next} {print | "sort -k1,1 -k2,2n"}'`` -- header lines first in their original order,
+    records by CHROM (byte order, i.e. ``LC_ALL=C``), then POS numerically, ties by the whole line (GNU sort's
+    last-resort comparison)."""
+    header = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if not l.startswith("#")]
+
+    def key(line):
+        cols = line.rstrip("\n").split("\t")
+        chrom = cols[0].encode()
+        try:
+            pos = float(cols[1].strip()) if len(cols) > 1 else 0.0
+        except ValueError:
+            pos = 0.0                                       # `sort -n` reads a non-number as 0
+        return (chrom, pos, line.encode())
+
+    return header + sorted(body, key=key)
+
+
 # ------------------------------------------------------------------------------------------
 # A17
 # ------------------------------------------------------------------------------------------

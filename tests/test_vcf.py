@@ -46,3 +46,23 @@ def test_two_base_delete_without_indel_threshold_is_a_nameerror():
     line = "c\t1\tBP=0.9;NV=0.1;HV=0.1;OV=0.8\tAT\tA\t50\t.\tDP=1;AF=1\tGT\t1\n"
     with pytest.raises(NameError):
         vcf.format_vcf_lines([line], vcf.FormatOptions())
+
+
+def test_sort_stage_matches_gnu_sort(tmp_path):
+    """call_variants.sh:151 pipes records through `sort -k1,1 -k2,2n`; ours must order identically (C locale)."""
+    import random
+    import shutil
+    import subprocess
+    if shutil.which("sort") is None or shutil.which("awk") is None:
+        pytest.skip("coreutils not available")
+    rng = random.Random(4)
+    chroms = ["chr1", "chr10", "chr2", "chrX", "chr20", "1", "chr1_random"]
+    lines = ["##fileformat=VCFv4.2\n", "#CHROM\tPOS\tID\n"]
+    for _ in range(400):
+        lines.append("\t".join((rng.choice(chroms), str(rng.choice([5, 50, 500, 1234567, 7])), "BP=%.8f" % rng.random(),
+                                rng.choice("ACGT"), rng.choice("ACGT"))) + "\n")
+    src = tmp_path / "in.vcf"
+    src.write_text("".join(lines))
+    cmd = "awk '$1 ~ /^#/ {print $0;next} {print $0 | \"sort -k1,1 -k2,2n\"}' %s" % src
+    want = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, env={"LC_ALL": "C", "PATH": os.environ["PATH"]}).stdout
+    assert "".join(vcf.sort_scored_vcf_lines(lines)) == want

@@ -1,0 +1,130 @@
+"""Fuzzing against the LIVE reference (only where /root/reference exists, i.e. the build container; skipped
+on the GPU box).  Complements the committed golden vectors: random structural configurations through the
+oracle vs the reference model, random allele records through the mask builders, random scored VCFs through
+format_vcf."""
+import contextlib
+import io
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden as G
+    m, d, u = G.import_reference()
+    return G, m, d, u
+
+
+def test_random_structural_configs_oracle_equals_reference(ref):
+    from oracle.dan_oracle import OracleSpec, random_state_dict, dan_forward_oracle
+    from dl4vc_amd import synth
+    G, m, d, u = ref
+    rng = random.Random(5)
+    for trial in range(6):
+        layers = rng.choice([3, 4, 5, 7])
+        pools = tuple(sorted(rng.sample(range(1, layers), rng.choice([0, 1, 2]) if layers > 2 else 0)))
+        spec = OracleSpec(reads=rng.choice([3, 5, 8]), c_init=rng.choice([4, 8, 12]), c_final=rng.choice([4, 8, 12]),
+                          layers=layers, pool_layers=pools, residual_start=rng.choice([0, 2, 3]),
+                          dil_mid=rng.choice([1, 2, 3]), dil_final=rng.choice([1, 2]), use_bn=rng.random() < 0.7,
+                          use_q=rng.random() < 0.7, use_strand=rng.random() < 0.7, use_mask=rng.random() < 0.8,
+                          bottleneck=rng.choice([0, 2, 4]), fc_sizes=(rng.choice([8, 12]), rng.choice([4, 6])))
+        if spec.residual_start > layers:
+            continue
+        sd = random_state_dict(spec, seed=300 + trial)
+        batch = synth.make_sites(3, reads=spec.reads, seed=400 + trial)
+        want = G.run_reference(m, spec, sd, batch, taps=False)
+        got = dan_forward_oracle(sd, spec, *batch.arrays())
+        for k, v in want.items():
+            np.testing.assert_allclose(got[k], v, atol=2e-5 * max(1.0, float(np.abs(v).max())), err_msg="%s %s" % (spec, k))
+
+
+def test_random_alleles_equal_reference(ref):
+    from dl4vc_amd import alleles
+    G, m, d, u = ref
+    rng = np.random.default_rng(9)
+    bases = "ACGT"
+    n_ok = n_err = 0
+    for trial in range(300):
+        window = rng.integers(1, 5, 201).astype(np.uint8)
+        for g in rng.integers(95, 115, rng.integers(0, 4)):
+            window[g] = 5                                           # gap columns around the centre
+        kind = rng.integers(0, 4)
+        c = "ATGC"[window[100] - 1] if window[100] in (1, 2, 3, 4) else "A"
+        tok2chr = {1: "A", 2: "T", 3: "G", 4: "C", 5: "N"}
+        if kind == 0:
+            ref_s, alt_s = c, bases[rng.integers(0, 4)]
+        elif kind == 1:
+            k = int(rng.integers(1, 6))
+            ref_s, alt_s = c, c + "".join(bases[i] for i in rng.integers(0, 4, k))
+        elif kind == 2:
+            k = int(rng.integers(1, 6))
+            tail = [tok2chr[int(t)] for t in window[101:140] if t != 5][:k]      # the deleted reference bases
+            ref_s, alt_s = c + "".join(tail), c
+        else:
+            ref_s = "".join(bases[i] for i in rng.integers(0, 4, rng.integers(1, 4)))
+            alt_s = "".join(bases[i] for i in rng.integers(0, 4, rng.integers(1, 4)))
+        rec = "\t".join(("chr1", "77", ".", ref_s, alt_s, "50", ".", "DP=10;AF=0.5", "GT:GQ", "1:50"))
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                want = d.get_read_mask_vectors(rec, reference=window.copy())
+                err = None
+            except Exception as e:          # noqa: BLE001
+                want, err = None, e
+        if err is None:
+            got = alleles.allele_mask_vectors(rec, window)
+            assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist(), rec
+            n_ok += 1
+        else:
+            with pytest.raises(Exception) as ex:
+                alleles.allele_mask_vectors(rec, window)
+            assert isinstance(ex.value, AssertionError) == isinstance(err, AssertionError), (rec, err, ex.value)
+            n_err += 1
+    assert n_ok > 100 and n_err > 10
+
+
+def test_random_scored_vcfs_through_format_vcf_equal_reference(ref, tmp_path):
+    import importlib
+    from dl4vc_amd import vcf
+    with contextlib.redirect_stdout(io.StringIO()):
+        fv = importlib.import_module("format_vcf")
+    assert fv.__file__.startswith(REF)
+    rng = np.random.default_rng(3)
+    header = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n"
+    alleles_pool = [("A", "G"), ("C", "T"), ("AT", "A"), ("A", "AT"), ("ATG", "A"), ("A", "ATGC"), ("G", "C"), ("T", "A")]
+    for trial in range(25):
+        lines, pos, used = [], 100, set()
+        for _ in range(int(rng.integers(1, 40))):
+            if rng.random() < 0.6:
+                pos += int(rng.integers(1, 50))
+                used = set()
+            cands = [a for a in alleles_pool if a not in used]      # identical lines trip an assert in the reference
+            if not cands:
+                continue
+            ref_s, alt_s = cands[int(rng.integers(0, len(cands)))]
+            used.add((ref_s, alt_s))
+            p = rng.dirichlet((0.6, 0.6, 0.6)) if rng.random() < 0.7 else np.array([rng.random() * 0.2, 0.05, 0.0])
+            nv, hv, ov = (float(x) for x in p / max(p.sum(), 1e-9)) if p.sum() > 0 else (1.0, 0.0, 0.0)
+            lines.append("\t".join(("chr2", str(pos), "BP=%.8f;NV=%.8f;HV=%.8f;OV=%.8f" % (1 - nv, nv, hv, ov), ref_s, alt_s,
+                                    "50", ".", "DP=30;AF=0.5", "GT:GQ", "1:50")))
+        text = header + "\n".join(lines) + "\n"
+        pin, pout = str(tmp_path / ("in%d.vcf" % trial)), str(tmp_path / ("out%d.vcf" % trial))
+        open(pin, "w").write(text)
+        a = types.SimpleNamespace(input_file=pin, output_file=pout, snp_threshold=0.1, indel_threshold=0.2,
+                                  long_indel_threshold=0.0, delete_threshold=0.0, snp_zygo_threshold=0.75,
+                                  indel_zygo_threshold=0.8, long_indel_zygo_threshold=0.5, delete_zygo_threshold=0.5,
+                                  multiallele_second_threshold=0.7, multiallele_homozygous_second_threshold=0.9, debug=False)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            fv.filter_format_vcf(a)
+        got = "".join(vcf.format_vcf_lines(text.splitlines(keepends=True), vcf.FormatOptions(**vcf.PIPELINE_OPTIONS)))
+        assert got == open(pout).read(), "trial %d" % trial
