@@ -81,12 +81,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DAN forward has no CPU path")
+    # rehearsal knobs (tests only): several ranks on ONE GPU cannot use RCCL ("duplicate GPU"), so the launch path can
+    # be exercised on a one-GPU box with BENCH_FORCE_DEVICE0=1 BENCH_DIST_BACKEND=gloo; the driver's runs use neither
+    if os.environ.get("BENCH_FORCE_DEVICE0"):
+        local_rank = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision)
     sd = random_state_dict(cfg, seed=0)
@@ -129,7 +137,7 @@ def main():
     n_launch, seg_ms = net.handle.kernel_stats("conv_segment")
     net.handle.profile(False)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -21,6 +21,20 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) bf8* gbf8_ptr;
 
+#ifdef DAN_STAMPS
+extern __device__ unsigned long long* g_stamps;
+#define STAMP16(k)                                                                                    \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
+        if (lane == 0 && (k) < 64) g_stamps[((size_t)blockIdx.x * NWAVE + wave) * 64 + (k)] = t_;     \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define STAMP16(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ v4f mfma_bf16(bf8 a, bf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ v4f splat4(float x) { return (v4f){x, x, x, x}; }
 // one compiler-visible instruction (an inline-asm v_max reading an MFMA result gets no hazard wait states)
@@ -197,6 +211,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
 #pragma unroll
     for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kq * 4;
 
+    STAMP16(0);
     auto block = [&](int l) { return a.wl + (size_t)l * W16_LAYER_BYTES; };
     auto conv_ptr = [&](int l) { return (gbf8_ptr)(block(l) + W16_CONV_OFF) + (wave * NT) * 64 + lane; };
     bf8 pre_conv[NT][2];
@@ -254,6 +269,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         }
     }
     __syncthreads();
+    STAMP16(1);
     if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out16<SPLIT, MT>(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
 
     for (int l = a.l_begin; l < a.l_end; ++l) {
@@ -284,7 +300,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
         }
+        [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+        STAMP16(sb + 0);
         gemm16<SPLIT, MT, KGC>(acc, xs, w_conv, W16_CONV_FRAGS, pre_conv, kg, 3, dil, lane);
+        STAMP16(sb + 1);
         {
             v4f sc[NT], sh[NT];
 #pragma unroll
@@ -305,7 +324,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                 }
             }
         }
+        STAMP16(sb + 2);
         __syncthreads();
+        STAMP16(sb + 3);
         if (residual) {
             v4f bres[NT];
 #pragma unroll
@@ -324,7 +345,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                 }
             }
             __syncthreads();
+            STAMP16(sb + 4);
             gemm16<SPLIT, MT, KGC>(acc, xs, w_res, W16_RES_FRAGS, pre_res, KG16_C, 1, 0, lane);
+            STAMP16(sb + 5);
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -343,14 +366,18 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                 for (int n = 0; n < NT; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
         }
         __syncthreads();
+        STAMP16(sb + 6);
         if (a.tap && a.tap_layer == l + 1) copy_out16<SPLIT, MT>(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
         if (a.has_hw)
             bottleneck16<SPLIT, MT>(xs, w_bot, W16_BOT_FRAGS, lc + CST_BBOT,
                                     a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+        STAMP16(sb + 7);
 #pragma unroll
         for (int n = 0; n < NT; ++n) { pre_conv[n][0] = pre_next[n][0]; pre_conv[n][1] = pre_next[n][1]; }
     }
+    STAMP16(62);
     copy_out16<SPLIT, MT>(xs, yrow, L, tid);
+    STAMP16(63);
 }
 
 void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s) {

@@ -14,7 +14,7 @@ pinned two ways (see ``oracle/gen_golden.py`` and ``tests/test_oracle_golden.py`
 * against golden vectors produced by importing the reference itself in the
   build container (``tests/golden/dan_*.npz``), and
 * live against the reference at full production shape when ``/root/reference``
-  is present (``tests/test_oracle_vs_reference.py``).
+  is present (``tests/test_vs_live_reference.py``, which also fuzzes random structural configurations).
 
 Data layout differs from the reference on purpose: all per-read tensors are
 ``[site][read][pos]`` uint8 (the HDF5-native order,

@@ -2,6 +2,7 @@
 // never timed for throughput: stamps serialise the schedule -- read the SHARES, not the length).
 //   hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/seg_probe.hip -o /tmp/seg_probe && /tmp/seg_probe [l_begin l_end]
 #include "../dl4vc_amd/csrc/dan_kernels.hip"
+#include "../dl4vc_amd/csrc/dan_kernels_bf16.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -11,6 +12,7 @@ using namespace dan;
 
 int main(int argc, char** argv) {
     const int l_begin = argc > 2 ? atoi(argv[1]) : 2, l_end = argc > 2 ? atoi(argv[2]) : 7;
+    const int precision = argc > 3 ? atoi(argv[3]) : 0;
     const int R = 64, L = 201, sites = 64, layers = 7, nwg = sites * R;
     std::vector<float> wl((size_t)layers * LAYER_STRIDE);
     srand(1);
@@ -41,7 +43,17 @@ int main(int argc, char** argv) {
     a.reads = a.qual = a.strand = a.ref = a.ref_mask = a.var_mask = d_u8;
     a.emb = d_emb; a.pe = d_pe; a.y = d_y; a.pool = l_begin ? d_pool : nullptr; a.h = d_h; a.h_layer_stride = (long long)hls;
     a.tap = nullptr; a.tap_layer = -1;
-    for (int rep = 0; rep < 3; ++rep) { launch_segment(a, sites, 0); CK(hipDeviceSynchronize()); }
+    char* d_wl16;
+    CK(hipMalloc(&d_wl16, (size_t)layers * W16_LAYER_BYTES));
+    CK(hipMemset(d_wl16, 0, (size_t)layers * W16_LAYER_BYTES));
+    Segment16Args q{};
+    q.wl = d_wl16; q.l_begin = a.l_begin; q.l_end = a.l_end; q.n_layers = a.n_layers; q.dil_mid = 2; q.dil_final = 2;
+    q.res_mask = a.res_mask; q.has_hw = 1; q.R = R; q.L = L; q.reads = q.qual = q.strand = q.ref = q.ref_mask = q.var_mask = d_u8;
+    q.emb = d_emb; q.pe = d_pe; q.y = d_y; q.pool = a.pool; q.h = d_h; q.h_layer_stride = a.h_layer_stride; q.tap = nullptr; q.tap_layer = -1;
+    for (int rep = 0; rep < 3; ++rep) {
+        if (precision == 0) launch_segment(a, sites, 0); else launch_segment16(q, sites, precision, 0);
+        CK(hipDeviceSynchronize());
+    }
     std::vector<unsigned long long> st(nst);
     CK(hipMemcpy(st.data(), d_st, nst * 8, hipMemcpyDeviceToHost));
     // median over workgroups/waves of each phase delta
