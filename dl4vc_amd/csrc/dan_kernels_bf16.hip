@@ -260,12 +260,26 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
     } else {
         const v4f* src = (const v4f*)yrow;
         const v4f* pl = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
+        // whole read (and pool image) in flight at once, then convert + store (see the fp32 kernel's prologue)
         const int n4 = L * (CPAD / 4);
-#pragma unroll 4
-        for (int i = tid; i < n4; i += SEG_THREADS) {
-            v4f v = src[i];
-            if (pl) v += pl[i];
-            store_cell<SPLIT, G::PLANE>(xs + (HALO + (i >> 5)) * S16 + (i & 31) * 4, v);
+        constexpr int NPF = (G::MPOS_ * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;
+        v4f vy[NPF];
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            vy[k] = (i < n4) ? src[i] : splat4(0.f);
+        }
+        if (pl) {
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int i = tid + k * SEG_THREADS;
+                if (i < n4) vy[k] += pl[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            if (i < n4) store_cell<SPLIT, G::PLANE>(xs + (HALO + (i >> 5)) * S16 + (i & 31) * 4, vy[k]);
         }
     }
     __syncthreads();
