@@ -8,8 +8,15 @@ namespace dan {
 // ---- fixed geometry of the fp32 path -----------------------------------------------------------
 constexpr int CPAD = 128;               // channel capacity of one activation row (c_init, c_final <= 128)
 constexpr int NWAVE = 8;                // waves per workgroup, two per SIMD: one covers the other's waits and epilogues
-constexpr int NT = 1;                   // 16-channel output tiles per wave   (CPAD / 16 / NWAVE)
 constexpr int SEG_THREADS = NWAVE * 64;
+// fp32 kernel: wave = (channel quarter cq = wave & 3, position half ph = wave >> 2).  It owns NT = 2 channel tiles
+// (32 channels) x the position tiles [7 ph, 7 ph + 7) -- 7 tiles for ph 0, 6 for ph 1; waves w and w + 4 share a
+// SIMD, so every SIMD carries 13 tile-pairs.  One ds_read_b128 then feeds 8 MFMAs (a 1-KiB LDS return costs the
+// matrix pipe ~7.4 cycles: tools/ubench/mfma_feed.hip).
+constexpr int NT = 2;
+constexpr int MTW = 7;                  // position tiles per wave (the upper half uses MT - MTW = 6 of them)
+// bf16 kernels: every wave owns one 16-channel tile x all position tiles
+constexpr int NT16 = 1;
 constexpr int MT = 13;                  // 16-position tiles per read         (L <= 208)
 constexpr int MPOS = MT * 16;           // 208
 constexpr int HALO = 4;                 // zero rows either side of the window (dilation <= 4)

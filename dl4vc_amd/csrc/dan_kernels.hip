@@ -4,7 +4,7 @@
 // W[out-channel][k] * X[k][position]  on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  One
 // workgroup (8 waves, two per SIMD) owns ONE READ: its 201 x 128 activation lives in LDS for the
 // whole segment of layers (position-major rows of 136 floats, zero halo rows either side), each wave
-// owns 16 output channels x all 13 position tiles (52 accumulator registers), weights stream from
+// owns 32 output channels x 7 (or 6) of the 13 position tiles (56 accumulator registers), weights stream from
 // L2 straight into A fragments (host-packed in fragment order, 1 KiB coalesced per wave-load), the
 // activation B fragments come from LDS as ds_read_b128 (the K order inside a 16-channel group is
 // permuted so that one 16-byte read feeds four MFMA k-steps).  ReLU, folded BatchNorm, the 1x1
@@ -60,19 +60,30 @@ typedef const __attribute__((address_space(1))) v4f* gv4f_ptr;     // global (no
 // and fmaxf costs two instructions (canonicalise + max).
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 
-__device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, gv4f_ptr wl, const v4f (&a_first)[NT],
-                                          int kg, int ntaps, int dil, int lane) {
+// One wave's share: acc[MTW][NT] = its 32 output channels x its position tiles [m_base, m_base + cnt), cnt = 7 or 6.
+__device__ __forceinline__ void gemm_tile(v4f (&acc)[NT], const v4f (&a)[NT], v4f& b, const float* next) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = mfma16(a[n][s], b[s], acc[n]);
+    b = *(const v4f*)next;
+}
+
+__device__ __forceinline__ void conv_gemm(v4f (&acc)[MTW][NT], const float* xs, gv4f_ptr wl, const v4f (&a_first)[NT],
+                                          int kg, int ntaps, int dil, int lane, int m_base, int cnt) {
     const int pos = lane & 15, kk = lane >> 4;
     const int total = ntaps * kg;
     const int t0 = (ntaps == 3) ? -dil : 0;
-    const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
-    v4f a_nxt[NT], b[MT];
+    const float* xrow = xs + (HALO + m_base * 16 + pos) * LDS_S + kk * 4;
+    const bool full = cnt == MTW;                              // wave-uniform
+    v4f a_nxt[NT], b[MTW];
 #pragma unroll
     for (int n = 0; n < NT; ++n) a_nxt[n] = a_first[n];
     {
         const float* xb = xrow + t0 * LDS_S;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) b[m] = *(const v4f*)(xb + m * 16 * LDS_S);
+        for (int m = 0; m < MTW - 1; ++m) b[m] = *(const v4f*)(xb + m * 16 * LDS_S);
+        b[MTW - 1] = full ? *(const v4f*)(xb + (MTW - 1) * 16 * LDS_S) : splat(0.f);
     }
     int t = 0, g = 0;
     for (int it = 0; it < total; ++it) {
@@ -87,19 +98,14 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MT][NT], const float* xs, g
         if (it + 1 == total) { tn = t; gn = g; }             // last step: harmless re-read
         const float* xn = xrow + (t0 + tn * dil) * LDS_S + gn * 16;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[n][s], b[m][s], acc[m][n]);
-            b[m] = *(const v4f*)(xn + m * 16 * LDS_S);
-        }
+        for (int m = 0; m < MTW - 1; ++m) gemm_tile(acc[m], a, b[m], xn + m * 16 * LDS_S);
         __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);         // the weight loads first
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MTW - 1; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);  // one tile's MFMAs
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
         }
+        if (full) gemm_tile(acc[MTW - 1], a, b[MTW - 1], xn + (MTW - 1) * 16 * LDS_S);
         t = tn; g = gn;
     }
 }
@@ -175,15 +181,17 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     const size_t read_idx = (size_t)site * a.R + r;
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
     const int pos = lane & 15, kk = lane >> 4;
+    const int cq = wave & 3, ph = wave >> 2;                  // channel quarter, position half
+    const int m_base = ph * MTW, cnt = ph ? MT - MTW : MTW;     // this wave's position tiles [m_base, m_base + cnt)
     int chb[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kk * 4;
+    for (int n = 0; n < NT; ++n) chb[n] = (cq * NT + n) * 16 + kk * 4;
 
     STAMP(0);
     // first conv's first weight fragments: in flight during the whole prologue
     v4f pre_conv[NT];
     {
-        gv4f_ptr w0 = (gv4f_ptr)(a.wl + (size_t)a.l_begin * LAYER_STRIDE + W_OFF) + (wave * NT) * 64 + lane;
+        gv4f_ptr w0 = (gv4f_ptr)(a.wl + (size_t)a.l_begin * LAYER_STRIDE + W_OFF) + (cq * NT) * 64 + lane;
 #pragma unroll
         for (int n = 0; n < NT; ++n) pre_conv[n] = w0[n * 64];
     }
@@ -265,8 +273,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         const bool residual = (a.res_mask >> l) & 1u;
         const int kg = (l == 0) ? KG0 : KGC;
         const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
-        gv4f_ptr w_conv = (gv4f_ptr)(wblk + W_OFF) + (wave * NT) * 64 + lane;
-        gv4f_ptr w_res = (gv4f_ptr)(wblk + WRES_OFF) + (wave * NT) * 64 + lane;
+        gv4f_ptr w_conv = (gv4f_ptr)(wblk + W_OFF) + (cq * NT) * 64 + lane;
+        gv4f_ptr w_res = (gv4f_ptr)(wblk + WRES_OFF) + (cq * NT) * 64 + lane;
         gv4f_ptr w_bot = (gv4f_ptr)(wblk + WBOT_OFF) + lane;
         // first fragments of the later GEMM stages of this layer and of the next conv: loaded now, used after
         // the conv GEMM, so their L2 latency is never exposed
@@ -277,19 +285,19 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             pre_next[n] = (l + 1 < a.l_end) ? w_conv[(size_t)(LAYER_STRIDE / 4) + n * 64] : splat(0.f);
         }
 
-        v4f acc[MT][NT];
+        v4f acc[MTW][NT];
         {
             v4f bias[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) bias[n] = *(const v4f*)(lc + CST_BIAS + chb[n]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
         }
         [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         STAMP(sb + 0);
-        conv_gemm(acc, xs, w_conv, pre_conv, kg, 3, dil, lane);
+        conv_gemm(acc, xs, w_conv, pre_conv, kg, 3, dil, lane, m_base, cnt);
         STAMP(sb + 1);
         // this wave's eight bottleneck weight fragments of the layer: issued now, consumed after the epilogue
         // (and the residual GEMM), so the ~1.5k-cycle loaded-L2 latency is off the critical path
@@ -299,24 +307,21 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
         }
-        // ---- epilogue: ReLU then eval-mode BatchNorm as one affine (model.py:749-751); rows >= L stay zero
+        // ---- epilogue: ReLU then eval-mode BatchNorm as one affine (model.py:749-751); rows >= L stay zero.
+        // Tile m of this wave is position tile m_base + m; the upper half's seventh slot (m = 6) does not exist.
         {
             v4f sc[NT], sh[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) { sc[n] = *(const v4f*)(lc + CST_SCALE + chb[n]); sh[n] = *(const v4f*)(lc + CST_SHIFT + chb[n]); }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
+            for (int m = 0; m < MTW; ++m) {
+                const bool live = ((m_base + m) * 16 + pos) < L;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     v4f v = acc[m][n];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]) * sc[n][j] + sh[n][j];
+                    for (int j = 0; j < 4; ++j) v[j] = live ? relu1(v[j]) * sc[n][j] + sh[n][j] : 0.f;
                     acc[m][n] = v;
-                }
-                if ((m + 1) * 16 > L) {                      // wave-uniform: only tiles that cross the window end
-                    const bool live = (m * 16 + pos) < L;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat(0.f);
                 }
             }
         }
@@ -332,29 +337,34 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
             if (!from_global) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MTW; ++m) {
+                    if (m < cnt) {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        v4f* cell = (v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]);
-                        const v4f old = *cell;
-                        *cell = acc[m][n];
-                        acc[m][n] = old + bres[n];
+                        for (int n = 0; n < NT; ++n) {
+                            v4f* cell = (v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]);
+                            const v4f old = *cell;
+                            *cell = acc[m][n];
+                            acc[m][n] = old + bres[n];
+                        }
                     }
+                }
             } else {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int p = m * 16 + pos;
+                for (int m = 0; m < MTW; ++m) {
+                    const int p = (m_base + m) * 16 + pos;
+                    if (m < cnt) {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const v4f old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat(0.f);
-                        *(v4f*)(xs + (HALO + p) * LDS_S + chb[n]) = acc[m][n];
-                        acc[m][n] = old + bres[n];
+                        for (int n = 0; n < NT; ++n) {
+                            const v4f old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat(0.f);
+                            *(v4f*)(xs + (HALO + p) * LDS_S + chb[n]) = acc[m][n];
+                            acc[m][n] = old + bres[n];
+                        }
                     }
                 }
             }
             __syncthreads();
             STAMP(sb + 4);
-            conv_gemm(acc, xs, w_res, pre_res, KGC, 1, 0, lane);
+            conv_gemm(acc, xs, w_res, pre_res, KGC, 1, 0, lane, m_base, cnt);
             STAMP(sb + 5);
             if (a.has_hw) {
 #pragma unroll
@@ -362,21 +372,22 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             }
             __syncthreads();
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if ((m + 1) * 16 > L) {
-                    const bool live = (m * 16 + pos) < L;
+            for (int m = 0; m < MTW; ++m) {
+                const int p = (m_base + m) * 16 + pos;
+                if (m < cnt) {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat(0.f);
+                    for (int n = 0; n < NT; ++n) *(v4f*)(xs + (HALO + p) * LDS_S + chb[n]) = (p < L) ? acc[m][n] : splat(0.f);
                 }
-#pragma unroll
-                for (int n = 0; n < NT; ++n) *(v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
             }
         } else {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MTW; ++m) {
+                if (m < cnt) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    *(v4f*)(xs + (HALO + m * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
+                    for (int n = 0; n < NT; ++n)
+                        *(v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
+                }
+            }
         }
         __syncthreads();
         STAMP(sb + 6);

@@ -81,16 +81,16 @@ __device__ __forceinline__ v4f load_cell(const __bf16* cell) {
 // implicit GEMM over taps x 32-channel k-groups.  wl points at this wave's first hi fragment; the lo plane of the
 // same block lies lo_off fragments further.  Fragment index of (step, tile n): step*(tiles*64) + n*64.
 template <bool SPLIT, int MT, int TILES>
-__device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT], const __bf16* xs, gbf8_ptr wl, int lo_off,
-                                       const bf8 (&a_first)[NT][2], int kg, int ntaps, int dil, int lane) {
+__device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT16], const __bf16* xs, gbf8_ptr wl, int lo_off,
+                                       const bf8 (&a_first)[NT16][2], int kg, int ntaps, int dil, int lane) {
     typedef Geo<SPLIT, MT> G;
     const int pos = lane & 15, kq = lane >> 4;
     const int total = ntaps * kg;
     const int t0 = (ntaps == 3) ? -dil : 0;
     const __bf16* xrow = xs + (HALO + pos) * S16 + kq * 8;
-    bf8 a_nxt[NT][2], bh[MT], bl[SPLIT ? MT : 1];
+    bf8 a_nxt[NT16][2], bh[MT], bl[SPLIT ? MT : 1];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { a_nxt[n][0] = a_first[n][0]; a_nxt[n][1] = a_first[n][1]; }
+    for (int n = 0; n < NT16; ++n) { a_nxt[n][0] = a_first[n][0]; a_nxt[n][1] = a_first[n][1]; }
     {
         const __bf16* xb = xrow + t0 * S16;
 #pragma unroll
@@ -101,12 +101,12 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT], const __bf16* xs, gbf
     }
     int t = 0, g = 0;
     for (int it = 0; it < total; ++it) {
-        bf8 a[NT][2];
+        bf8 a[NT16][2];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { a[n][0] = a_nxt[n][0]; a[n][1] = a_nxt[n][1]; }
+        for (int n = 0; n < NT16; ++n) { a[n][0] = a_nxt[n][0]; a[n][1] = a_nxt[n][1]; }
         const int nx = (it + 1 < total) ? it + 1 : it;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int n = 0; n < NT16; ++n) {
             a_nxt[n][0] = wl[(size_t)nx * (TILES * 64) + n * 64];
             if (SPLIT) a_nxt[n][1] = wl[(size_t)nx * (TILES * 64) + n * 64 + lo_off];
         }
@@ -117,20 +117,20 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT], const __bf16* xs, gbf
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(a[n][0], bh[m], acc[m][n]);
+            for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][0], bh[m], acc[m][n]);
             if (SPLIT) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(a[n][1], bh[m], acc[m][n]);
+                for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][1], bh[m], acc[m][n]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(a[n][0], bl[m], acc[m][n]);
+                for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][0], bl[m], acc[m][n]);
             }
             bh[m] = *(const bf8*)(xn + m * 16 * S16);
             if (SPLIT) bl[m] = *(const bf8*)(xn + m * 16 * S16 + G::PLANE);
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, NT * G::NP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NT16 * G::NP, 0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NT * (SPLIT ? 3 : 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT16 * (SPLIT ? 3 : 1), 0);
             __builtin_amdgcn_sched_group_barrier(0x100, G::NP, 0);
         }
         t = tn; g = gn;
@@ -207,18 +207,18 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
     const size_t read_idx = (size_t)site * a.R + r;
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
     const int pos = lane & 15, kq = lane >> 4;
-    int chb[NT];
+    int chb[NT16];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kq * 4;
+    for (int n = 0; n < NT16; ++n) chb[n] = (wave * NT16 + n) * 16 + kq * 4;
 
     STAMP16(0);
     auto block = [&](int l) { return a.wl + (size_t)l * W16_LAYER_BYTES; };
-    auto conv_ptr = [&](int l) { return (gbf8_ptr)(block(l) + W16_CONV_OFF) + (wave * NT) * 64 + lane; };
-    bf8 pre_conv[NT][2];
+    auto conv_ptr = [&](int l) { return (gbf8_ptr)(block(l) + W16_CONV_OFF) + (wave * NT16) * 64 + lane; };
+    bf8 pre_conv[NT16][2];
     {
         gbf8_ptr w0 = conv_ptr(a.l_begin);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { pre_conv[n][0] = w0[n * 64]; pre_conv[n][1] = w0[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)]; }
+        for (int n = 0; n < NT16; ++n) { pre_conv[n][0] = w0[n * 64]; pre_conv[n][1] = w0[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)]; }
     }
     for (int i = tid; i < G::PLANES * G::PLANE / 8; i += SEG_THREADS) ((v4f*)xs)[i] = splat4(0.f);
     for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
@@ -292,11 +292,11 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         const int kg = (l == 0) ? KG16_0 : KG16_C;
         const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
         gbf8_ptr w_conv = conv_ptr(l);
-        gbf8_ptr w_res = (gbf8_ptr)(block(l) + W16_RES_OFF) + (wave * NT) * 64 + lane;
+        gbf8_ptr w_res = (gbf8_ptr)(block(l) + W16_RES_OFF) + (wave * NT16) * 64 + lane;
         gbf8_ptr w_bot = (gbf8_ptr)(block(l) + W16_BOT_OFF) + lane;
-        bf8 pre_res[NT][2], pre_next[NT][2];
+        bf8 pre_res[NT16][2], pre_next[NT16][2];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int n = 0; n < NT16; ++n) {
             pre_res[n][0] = w_res[n * 64];
             pre_res[n][1] = w_res[n * 64 + (SPLIT ? W16_RES_FRAGS : 0)];
             gbf8_ptr wn = (l + 1 < a.l_end) ? conv_ptr(l + 1) : w_conv;
@@ -304,28 +304,28 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
             pre_next[n][1] = wn[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)];
         }
 
-        v4f acc[MT][NT];
+        v4f acc[MT][NT16];
         {
-            v4f bias[NT];
+            v4f bias[NT16];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bias[n] = *(const v4f*)(lc + CST_BIAS + chb[n]);
+            for (int n = 0; n < NT16; ++n) bias[n] = *(const v4f*)(lc + CST_BIAS + chb[n]);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
+                for (int n = 0; n < NT16; ++n) acc[m][n] = bias[n];
         }
         [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         STAMP16(sb + 0);
         gemm16<SPLIT, MT, KGC>(acc, xs, w_conv, W16_CONV_FRAGS, pre_conv, kg, 3, dil, lane);
         STAMP16(sb + 1);
         {
-            v4f sc[NT], sh[NT];
+            v4f sc[NT16], sh[NT16];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) { sc[n] = *(const v4f*)(lc + CST_SCALE + chb[n]); sh[n] = *(const v4f*)(lc + CST_SHIFT + chb[n]); }
+            for (int n = 0; n < NT16; ++n) { sc[n] = *(const v4f*)(lc + CST_SCALE + chb[n]); sh[n] = *(const v4f*)(lc + CST_SHIFT + chb[n]); }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
+                for (int n = 0; n < NT16; ++n) {
                     v4f v = acc[m][n];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = relu1f(v[j]) * sc[n][j] + sh[n][j];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                 if ((m + 1) * 16 > L) {
                     const bool live = (m * 16 + pos) < L;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat4(0.f);
+                    for (int n = 0; n < NT16; ++n) acc[m][n] = live ? acc[m][n] : splat4(0.f);
                 }
             }
         }
@@ -342,15 +342,15 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         __syncthreads();
         STAMP16(sb + 3);
         if (residual) {
-            v4f bres[NT];
+            v4f bres[NT16];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bres[n] = *(const v4f*)(lc + CST_BRES + chb[n]);
+            for (int n = 0; n < NT16; ++n) bres[n] = *(const v4f*)(lc + CST_BRES + chb[n]);
             const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int p = m * 16 + pos;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
+                for (int n = 0; n < NT16; ++n) {
                     __bf16* cell = xs + (HALO + p) * S16 + chb[n];
                     v4f old = load_cell<SPLIT, G::PLANE>(cell);
                     if (from_global) old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat4(0.f);
@@ -368,16 +368,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                 if ((m + 1) * 16 > L) {
                     const bool live = (m * 16 + pos) < L;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = live ? acc[m][n] : splat4(0.f);
+                    for (int n = 0; n < NT16; ++n) acc[m][n] = live ? acc[m][n] : splat4(0.f);
                 }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
+                for (int n = 0; n < NT16; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
             }
         } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
+                for (int n = 0; n < NT16; ++n) store_cell<SPLIT, G::PLANE>(xs + (HALO + m * 16 + pos) * S16 + chb[n], acc[m][n]);
         }
         __syncthreads();
         STAMP16(sb + 6);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                                     a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
         STAMP16(sb + 7);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { pre_conv[n][0] = pre_next[n][0]; pre_conv[n][1] = pre_next[n][1]; }
+        for (int n = 0; n < NT16; ++n) { pre_conv[n][0] = pre_next[n][0]; pre_conv[n][1] = pre_next[n][1]; }
     }
     STAMP16(62);
     copy_out16<SPLIT, MT>(xs, yrow, L, tid);
