@@ -477,60 +477,74 @@ void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, i
 // tiles are summed through LDS in fixed wave order (deterministic).
 // ------------------------------------------------------------------------------------------------
 constexpr int HW_WAVES = 8;
+constexpr int HW_RT = 2;                                    // 16-read row tiles per workgroup (weights amortised over 32 reads)
 __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ h, long long hls,
                                                       const v4f* __restrict__ wc, long long wcls,
                                                       const float* __restrict__ bc, float* __restrict__ feat,
                                                       long long fs, int feat_off, int n_rows, int R, int L, int H) {
-    __shared__ float part[HW_WAVES][2][256];
+    __shared__ float part[HW_WAVES][HW_RT][2][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
     const int layer = blockIdx.y;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * (16 * HW_RT);
     const size_t K = (size_t)L * HPAD;
     const int G = L * 2;
     const int g_lo = (int)((long long)G * wave / HW_WAVES), g_hi = (int)((long long)G * (wave + 1) / HW_WAVES);
-    const float* arow = h + (size_t)layer * hls + (size_t)min(row0 + r16, n_rows - 1) * K + kk * 4;
+    const float* arow[HW_RT];
+#pragma unroll
+    for (int i = 0; i < HW_RT; ++i) arow[i] = h + (size_t)layer * hls + (size_t)min(row0 + 16 * i + r16, n_rows - 1) * K + kk * 4;
     const v4f* wl = wc + (size_t)layer * wcls + lane;
-    v4f acc[2] = {splat(0.f), splat(0.f)};
+    v4f acc[HW_RT][2];
+#pragma unroll
+    for (int i = 0; i < HW_RT; ++i) { acc[i][0] = splat(0.f); acc[i][1] = splat(0.f); }
     constexpr int D = 4;                                    // k-groups in flight per wave
-    v4f ar[D], b0[D], b1[D];
+    v4f ar[D][HW_RT], b0[D], b1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const int g = min(g_lo + d, g_hi - 1);
-        ar[d] = *(const v4f*)(arow + (size_t)g * 16);
+#pragma unroll
+        for (int i = 0; i < HW_RT; ++i) ar[d][i] = *(const v4f*)(arow[i] + (size_t)g * 16);
         b0[d] = wl[((size_t)g * 2) * 64];
         b1[d] = wl[((size_t)g * 2 + 1) * 64];
     }
     for (int g = g_lo; g < g_hi; g += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const v4f a = ar[d], w0 = b0[d], w1 = b1[d];
+            v4f a[HW_RT];
+#pragma unroll
+            for (int i = 0; i < HW_RT; ++i) a[i] = ar[d][i];
+            const v4f w0 = b0[d], w1 = b1[d];
             const int gn = min(g + d + D, g_hi - 1);
-            ar[d] = *(const v4f*)(arow + (size_t)gn * 16);
+#pragma unroll
+            for (int i = 0; i < HW_RT; ++i) ar[d][i] = *(const v4f*)(arow[i] + (size_t)gn * 16);
             b0[d] = wl[((size_t)gn * 2) * 64];
             b1[d] = wl[((size_t)gn * 2 + 1) * 64];
             if (g + d < g_hi) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[0] = mfma16(a[s], w0[s], acc[0]);
-                    acc[1] = mfma16(a[s], w1[s], acc[1]);
-                }
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < HW_RT; ++i) {
+                        acc[i][0] = mfma16(a[i][s], w0[s], acc[i][0]);
+                        acc[i][1] = mfma16(a[i][s], w1[s], acc[i][1]);
+                    }
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < HW_RT; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) part[wave][j][lane * 4 + jj] = acc[j][jj];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) part[wave][i][j][lane * 4 + jj] = acc[i][j][jj];
     __syncthreads();
-    {
-        // element e of tile j: lane = e >> 2, jj = e & 3  ->  row = row0 + 4*(lane>>4) + jj, o = 16 j + (lane & 15)
-        const int j = tid >> 8, e = tid & 255;
+    // element e of tile (i, j): lane = e >> 2, jj = e & 3  ->  row = row0 + 16 i + 4*(lane>>4) + jj, o = 16 j + (lane & 15)
+    for (int idx = tid; idx < HW_RT * 2 * 256; idx += 512) {
+        const int i = idx >> 9, j = (idx >> 8) & 1, e = idx & 255;
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < HW_WAVES; ++w) sum += part[w][j][e];
+        for (int w = 0; w < HW_WAVES; ++w) sum += part[w][i][j][e];
         const int ln = e >> 2, jj = e & 3;
-        const int row = row0 + 4 * (ln >> 4) + jj, o = 16 * j + (ln & 15);
+        const int row = row0 + 16 * i + 4 * (ln >> 4) + jj, o = 16 * j + (ln & 15);
         if (o < H && row < n_rows) {
             const int site = row / R, r = row - site * R;
             feat[(size_t)site * fs + feat_off + (size_t)layer * H * R + (size_t)o * R + r] =
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ 
 void launch_highway(const float* h, long long hls, const float* wc, long long wcls, const float* bc, float* feat,
                     long long fs, int feat_off, int n_sites, int R, int L, int H, int layers, hipStream_t s) {
     const int n_rows = n_sites * R;
-    hipLaunchKernelGGL(highway_kernel, dim3((n_rows + 15) / 16, layers), dim3(512), 0, s, h, hls, (const v4f*)wc,
+    hipLaunchKernelGGL(highway_kernel, dim3((n_rows + 16 * HW_RT - 1) / (16 * HW_RT), layers), dim3(512), 0, s, h, hls, (const v4f*)wc,
                        wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H);
 }
 
