@@ -161,3 +161,19 @@ def test_genotype_calls_identical_to_oracle():
     near += int((np.abs(want["vt_prob"][:, 2:3] - np.array([[0.75, 0.8]])).min(axis=1) < 1e-4).sum())
     print("sites within 1e-4 of a genotype threshold: %d of %d" % (near, len(batch)))
     assert np.abs(got["vt_prob"] - want["vt_prob"]).max() < SCORE_ATOL
+
+
+@pytest.mark.parametrize("length", [120, 208])
+def test_other_window_lengths(length):
+    """single_read_len is a constructor argument of the reference (model.py:41); the fp32 kernel takes any window
+    up to 13 x 16 = 208 columns (rows beyond L stay zero through every layer)."""
+    cfg = DanConfig(reads=6, length=length, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))
+    sd = random_state_dict(cfg, seed=9)
+    batch = synth.make_sites(4, reads=6, length=length, seed=10)
+    net = DanNet(cfg).load_state_dict(sd)
+    got = net.forward_u8(*batch.arrays(), aux=True)
+    net.close()
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    for k in ("vt_logits", "bin_logits", "vb"):
+        close(got[k], want[k], TAP_RTOL, k)
+    close(got["vt_prob"], want["vt_prob"], SCORE_ATOL, "vt_prob")
