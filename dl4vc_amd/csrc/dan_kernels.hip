@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) void read_mean_kernel(const v4f* __restrict__ 
     const int site = blockIdx.y;
     const v4f* src = y + (size_t)site * R * n4 + i;
     v4f sum = splat(0.f);
+#pragma unroll 8
     for (int r = 0; r < R; ++r) sum += src[(size_t)r * n4];
     pool[(size_t)site * n4 + i] = sum / splat((float)R);
 }
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__
             const v4f* src = y + (size_t)site * R * n4 + (size_t)p * (CPAD / 4) + c4;
             mx = src[0];
             v4f sum = src[0];
+#pragma unroll 8
             for (int r = 1; r < R; ++r) {
                 const v4f v = src[(size_t)r * n4];
 #pragma unroll

@@ -27,21 +27,7 @@
 #include <thread>
 #include <vector>
 
-extern "C" {
-typedef struct dl_loader dl_loader_t;
-int dl_open(const char* hdf_path, const char* libhdf5_path, int32_t reads, int64_t lo, int64_t hi, int32_t batch_sites,
-            uint64_t seed, int32_t use_seed, int32_t threads, int32_t prefetch, dl_loader_t** out);
-int64_t dl_num_records(const dl_loader_t* l);
-int64_t dl_num_sites(const dl_loader_t* l);   /* hi - lo */
-int32_t dl_window(const dl_loader_t* l);
-int64_t dl_next(dl_loader_t* l, uint8_t* reads, uint8_t* qual, uint8_t* strand, uint8_t* ref, uint8_t* ref_mask,
-                uint8_t* var_mask, char* vcfrec /*[n][129]*/, int32_t* num_reads, uint8_t* blacklist);
-void dl_close(dl_loader_t* l);
-const char* dl_last_error(const dl_loader_t* l);
-/* exposed for tests: the numpy-compatible subset draw and the allele masks */
-int dl_select_rows(uint32_t seed, int32_t num_reads, int32_t stored_rows, int32_t max_reads, int32_t* rows_out);
-int dl_allele_masks(const char* vcfrec, const uint8_t* window /*[201]*/, uint8_t* ref_mask, uint8_t* var_mask);
-}
+#include "../../include/dl4vc_loader.h"
 
 namespace {
 

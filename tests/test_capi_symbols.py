@@ -33,6 +33,19 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, n), n
 
 
+def test_loader_header_symbols_exported():
+    from dl4vc_amd import loader
+    if not loader.available():
+        import __graft_entry__ as g
+        g.build()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dl4vc_loader.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(dl_[a-z_]+)\s*\(", text)))
+    assert set(names) == set(loader.SYMBOLS)
+    nl = loader.load_library()
+    for n in names:
+        assert hasattr(nl, n), n
+
+
 def test_abi_version(lib):
     assert lib.dan_abi_version() == capi.ABI_VERSION
 
