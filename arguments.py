@@ -68,6 +68,8 @@ _EXTRA = [
     ("--shard", "str", "", "i/n: process only the i-th of n contiguous site shards (multi-GPU launch sets this)"),
     ("--precision", "str", "fp32", "conv-stack arithmetic: fp32 (exact fp32 MFMA, default), bf16x3 (split bf16, scores "
                                    "within 1e-4, ~2.3x faster) or bf16"),
+    ("--conv-algo", "str", "auto", "fp32 conv form: auto (Winograd F(2,3) where every layer after the first has "
+                                   "dilation 2), direct, or winograd"),
 ]
 
 _TYPES = {"int": int, "float": float, "str": str}

@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 MFMA (headline), 1 bf16x3 split, 2 bf16")
     ap.add_argument("--window", type=int, default=201)
+    ap.add_argument("--conv-algo", type=int, default=0, help="fp32 conv form: 0 auto (Winograd F(2,3) on the dilation-2 "
+                                                              "layers), 1 direct, 2 winograd")
     args = ap.parse_args()
 
     import torch
@@ -96,7 +98,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision)
+    cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision, conv_algo=args.conv_algo)
     sd = random_state_dict(cfg, seed=0)
     net = DanNet(cfg, device_id=local_rank, chunk_sites=args.chunk_sites).load_state_dict(sd)
 
@@ -157,6 +159,10 @@ def main():
         seg_flops_site = 2.0 * cfg.reads * cfg.length * macs_pos
         seg_flops_total = seg_flops_site * B * args.steps
         achieved = seg_flops_total / (seg_ms * 1e-3) / 1e12 if seg_ms > 0 else None
+        # MFMA FLOPs the kernel actually issues: fewer than the algorithmic count when the dilation-2 layers run in
+        # Winograd F(2,3) form (4 channel GEMMs per 2 outputs instead of 6); tile padding not counted
+        exec_macs = cfg.executed_macs_per_position() - cfg.layers * cfg.bottleneck * cfg.bottleneck
+        executed = achieved * exec_macs / macs_pos if achieved else None
         peak = PEAK_F32_MFMA_TFLOPS if cfg.precision == 0 else PEAK_BF16_MFMA_TFLOPS
         line = {
             "metric": "candidate-variants/sec (DAN fwd, %d reads x %d bp)" % (cfg.reads, cfg.length),
@@ -171,6 +177,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
+                         "conv_algo": "winograd_f23" if cfg.winograd_applies() else "direct",
+                         "executed": round(executed, 3) if executed else None,
+                         "executed_frac": round(executed / peak, 4) if executed else None,
                          "kernel": "dan::segment_kernel", "launches": n_launch,
                          "avg_launch_ms": round(seg_ms / max(n_launch, 1), 4),
                          "gflop_per_launch": round(seg_flops_total / max(n_launch, 1) / 1e9, 3),

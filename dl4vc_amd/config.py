@@ -46,6 +46,7 @@ class DanConfig:
     fc_sizes: Tuple[int, ...] = (1024, 256)  # layer_sizes (constructor default, model.py:35)
     embed_dim: int = 20                      # embed_dim   (constructor default)
     precision: int = PRECISION_F32
+    conv_algo: int = 0                       # fp32 path: 0 auto, 1 direct 3-tap GEMM, 2 Winograd F(2,3) (include/dl4vc_dan.h)
 
     def __post_init__(self):
         object.__setattr__(self, "pool_layers", tuple(int(p) for p in self.pool_layers))
@@ -104,6 +105,22 @@ class DanConfig:
         fc += sizes[-1] * 27
         return 2.0 * (self.reads * self.length * self.macs_per_position() + fc)
 
+    def winograd_applies(self) -> bool:
+        """The fp32 path runs the 3-tap convolutions after the first layer in Winograd F(2,3) form when all of them have
+        dilation 2 (the production network) and ``conv_algo`` does not force the direct form."""
+        dil_ok = (self.layers < 3 or self.dil_mid == 2) and (self.layers < 2 or self.dil_final == 2)
+        return self.precision == PRECISION_F32 and dil_ok and self.conv_algo != 1 and self.layers > 1
+
+    def executed_macs_per_position(self) -> float:
+        """MFMA multiply-accumulates per (read, position) actually issued: ``macs_per_position`` with the Winograd layers'
+        3-tap term replaced by 4 GEMMs per 2 outputs (2 * cin * cout).  Tile padding is not counted."""
+        total = float(self.macs_per_position())
+        if self.winograd_applies():
+            for l in range(2, self.layers + 1):
+                cin, cout, _ = self.layer_dims(l)
+                total -= cin * cout
+        return total
+
     def input_bytes_per_site(self) -> int:
         return 3 * self.reads * self.length + 3 * self.length
 
@@ -124,6 +141,8 @@ class DanConfig:
                 raise UnsupportedModelOption("pool layer %d must lie in 1..layers-1" % p)
         if self.bottleneck < 0 or len(self.fc_sizes) != 2:
             raise UnsupportedModelOption("bottleneck >= 0 and exactly two FC layers required")
+        if self.conv_algo not in (0, 1, 2):
+            raise UnsupportedModelOption("conv_algo must be 0 (auto), 1 (direct) or 2 (winograd)")
         if self.embed_dim != 20:
             raise UnsupportedModelOption("embed_dim is fixed at 20 in the reference's scripts")
 

@@ -44,6 +44,7 @@ struct dan_handle {
     int64_t F_stride = 0;                    // padded to a multiple of 16
     int n0_stride = 0;                       // fc_sizes[0] padded to a multiple of 16 (K of the second FC)
     int chunk = 0, max_batch = 0;
+    int wino = 0;                            // dilation-2 layers in Winograd F(2,3) form
     int tap_layer = -1;
     int last_chunk_sites = 0;
     int64_t last_batch = 0;
@@ -237,12 +238,18 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         return fail(nullptr, DAN_ERR_INVALID_ARG, "Do not allow residuals starting at conv layer %d", c.residual_start);   // model.py:209
     if ((c.pool_layers_mask & 1u) || (c.pool_layers_mask >> c.layers))
         return fail(nullptr, DAN_ERR_INVALID_ARG, "pool layers must lie in 1..layers-1");
+    // Winograd F(2,3) form (dan_kernels.hip): fp32 path, and every conv after the first must have dilation 2
+    const bool wino_ok = c.precision == 0 && (c.layers < 3 || c.dil_mid == 2) && (c.layers < 2 || c.dil_final == 2);
+    if (c.conv_algo < 0 || c.conv_algo > 2) return fail(nullptr, DAN_ERR_INVALID_ARG, "conv_algo %d unknown (0 = auto, 1 = direct, 2 = winograd)", c.conv_algo);
+    if (c.conv_algo == 2 && !wino_ok)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "conv_algo 2 (winograd) needs precision 0 and dilation 2 on every conv layer after the first");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c.device_id < 0 || c.device_id >= ndev)
         return fail(nullptr, DAN_ERR_NO_DEVICE, "no HIP device %d (found %d): the DAN forward has no CPU path", c.device_id, ndev);
     dan_handle* h = new dan_handle();
     h->cfg = c;
     h->chunk = c.chunk_sites > 0 ? c.chunk_sites : 128;
+    h->wino = wino_ok && c.conv_algo != 1;
     h->max_batch = c.max_batch > 0 ? c.max_batch : 4096;
     h->max_batch = ((h->max_batch + h->chunk - 1) / h->chunk) * h->chunk;
     h->F = 2 * c.c_final * c.length + c.layers * c.bottleneck * c.reads;
@@ -314,6 +321,15 @@ int dan_finalize(dan_t* h) {
         };
         std::vector<float> packed = pack_frag(3, kg, KGC, Wf);
         std::copy(packed.begin(), packed.end(), blk + W_OFF);
+        if (l > 0) {
+            // Winograd F(2,3) weight transform U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2], formed in double
+            auto Wu = [&](int o, int cc, int k) -> float {
+                const double g0 = Wf(o, cc, 0), g1 = Wf(o, cc, 1), g2 = Wf(o, cc, 2);
+                return k == 0 ? (float)g0 : k == 1 ? (float)((g0 + g1 + g2) * 0.5) : k == 2 ? (float)((g0 - g1 + g2) * 0.5) : (float)g2;
+            };
+            std::vector<float> pw = pack_frag(4, KGC, KGC, Wu);
+            std::copy(pw.begin(), pw.end(), blk + WW_OFF);
+        }
         char* blk16 = c.precision ? wl16.data() + (size_t)l * W16_LAYER_BYTES : nullptr;
         if (blk16) {
             auto Wf16 = [&](int o, int cc, int t) -> float { return Wf(o, cc, t); };   // channels beyond kg*16 read as 0
@@ -470,6 +486,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                                       ((h->tap_layer == 0 && sg == 0) || (h->tap_layer > a.l_begin && h->tap_layer <= a.l_end));
                 a.tap = tap_here ? h->d_tap : nullptr;
                 a.tap_layer = h->tap_layer;
+                a.wino = h->wino;
                 EventPair ev{};
                 int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (c.precision == 0) {

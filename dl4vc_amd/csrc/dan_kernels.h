@@ -42,7 +42,9 @@ constexpr int WBOT_OFF = WRES_OFF + KGC * KGC * 256;         // 65536
 constexpr int CST_OFF = WBOT_OFF + KGC * 2 * 256;            // 69632
 constexpr int CST_BIAS = 0, CST_SCALE = CPAD, CST_SHIFT = 2 * CPAD, CST_BRES = 3 * CPAD, CST_BBOT = 4 * CPAD;
 constexpr int CST_FLOATS = 4 * CPAD + HPAD;                  // 544
-constexpr int LAYER_STRIDE = CST_OFF + CST_FLOATS + 32;      // 70208 floats (16-byte aligned blocks)
+//   [WW_OFF)   Winograd F(2,3) weights U_k of the conv   [k 4][kg 8][tile 8][lane 64][4]   (layers > 1 only)
+constexpr int WW_OFF = CST_OFF + CST_FLOATS + 32;            // 70208
+constexpr int LAYER_STRIDE = WW_OFF + 4 * KGC * KGC * 256;   // 135744 floats (16-byte aligned blocks)
 constexpr int MAX_LAYERS = 16;
 
 struct SegmentArgs {
@@ -64,6 +66,7 @@ struct SegmentArgs {
     long long h_layer_stride;    // floats between layers of h
     float* tap;                  // [site][read][L][CPAD] or nullptr
     int tap_layer;               // 0 = encoded input, l = after conv layer l (1-based), -1 = none
+    int wino;                    // 1: dilation-2 layers after the first run in Winograd F(2,3) form
 };
 
 void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s);

@@ -110,6 +110,113 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MTW][NT], const float* xs, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2,3) form of the dilation-2 convolutions (exact-fp32 MFMAs, 4 channel GEMMs per 2 outputs instead of 6):
+//   outputs y(P), y(P+2) of one tile come from x(P-2), x(P), x(P+2), x(P+4):
+//     V = [x0 - x2, x1 + x2, x2 - x1, x1 - x3],  M_k = U_k V_k  (U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2], host-packed),
+//     y(P) = M0 + M1 + M2,  y(P+2) = M1 - M2 - M3.
+// Mapping: every wave owns ONE 16-channel tile (wave index) and all positions.  MFMA column n of position tile m is the
+// Winograd tile with base  P = hf*WHB + 4*(q*MW + m) + c,  c = n&1, hf = (n>>2)&1, q = ((n>>1)&1) + 2*(((n>>3)^(n>>2))&1):
+// a lane walks consecutive tiles of one parity class, so two of its four input rows carry over from tile to tile
+// (2 ds_read_b128 per 16 MFMAs), and the upper half of the read is tiled from position 102 (== 2 mod 4) so that the 16 lanes
+// of every ds_read_b128 group touch rows of all 8 residues mod 8 -- conflict-free with the 136-float row stride.
+// Lower-half lanes own positions [0, 102), upper-half lanes [102, 208); tiles outside (and the rows they read, which
+// may run past the activation into the constants that follow it in LDS) produce columns nobody stores.
+constexpr int MW = 7;                   // Winograd tiles per lane
+constexpr int WHB = 102;                // first position of the upper half's tiling
+static_assert((HALO + WHB + 4 * (4 * MW - 1) + 1 + 4 + 1) * LDS_S <= LDS_ROWS * LDS_S + MAX_LAYERS * CST_FLOATS, "wino reads stay inside LDS");
+static_assert(WHB + 4 * (4 * MW - 1) + 3 >= MPOS - 1 && 4 * (4 * MW - 1) + 3 >= WHB - 1, "wino tiling covers the read");
+
+__device__ __forceinline__ int wino_base(int lane) {
+    const int n = lane & 15;
+    const int c = n & 1, hf = (n >> 2) & 1, q = ((n >> 1) & 1) + 2 * (((n >> 3) ^ (n >> 2)) & 1);
+    return hf * WHB + 4 * q * MW + c;
+}
+
+// acc[m][k] += U_k[own 16 channels][all 128 in-channels] * V_k[tile m]
+typedef float v2f __attribute__((ext_vector_type(2)));
+// a - b as two v_pk_fma_f32 (b * m1 + a with m1 = -1.0 in a register the compiler cannot see through: hipcc turns a
+// v2f32 fsub, or an fma by a literal -1, into two scalar v_sub_f32; every VALU instruction costs the SIMD 3-5 cycles of
+// MFMA issue -- tools/ubench/mfma_valu.hip -- so the packed form halves the price of the input transform)
+__device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
+    const v2f lo = __builtin_elementwise_fma((v2f){b[0], b[1]}, m1, (v2f){a[0], a[1]});
+    const v2f hi = __builtin_elementwise_fma((v2f){b[2], b[3]}, m1, (v2f){a[2], a[3]});
+    return (v4f){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
+    v4f a_nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a_nxt[k] = a_first[k];
+    v4f xa = *(const v4f*)(xrow), xb = *(const v4f*)(xrow + 2 * LDS_S), xc = *(const v4f*)(xrow + 4 * LDS_S),
+        xd = *(const v4f*)(xrow + 6 * LDS_S);
+    float neg1 = -1.f;
+    asm volatile("" : "+v"(neg1));
+    const v2f m1 = {neg1, neg1};
+    for (int g = 0; g < KGC; ++g) {
+        v4f a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = a_nxt[k];
+        const int gn = (g + 1 < KGC) ? g + 1 : g;            // last step: harmless re-read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a_nxt[k] = wl[(size_t)(k * KGC + gn) * (KGC * 64)];
+        const float* xg = xrow + g * 16;
+        const float* xn = xrow + gn * 16;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            v4f v[4];
+            v[0] = pk_sub(xa, xc, m1); v[1] = xb + xc; v[2] = pk_sub(xc, xb, m1); v[3] = pk_sub(xb, xd, m1);
+            if (m + 1 < MW) {
+                xa = xc; xb = xd;
+                xc = *(const v4f*)(xg + (4 * m + 8) * LDS_S);
+                xd = *(const v4f*)(xg + (4 * m + 10) * LDS_S);
+            } else {
+                xa = *(const v4f*)(xn); xb = *(const v4f*)(xn + 2 * LDS_S);
+                xc = *(const v4f*)(xn + 4 * LDS_S); xd = *(const v4f*)(xn + 6 * LDS_S);
+            }
+            // Take turns with the SIMD's other wave, one tile each: the arbiter serves the highest s_setprio first and
+            // the OLDER wave on a tie, so without this the older wave keeps the matrix pipe to itself, the younger one
+            // only fills its gaps and then runs alone, exposing its own VALU/LDS gaps.  A wave asks at priority 2,
+            // holds the pipe at 3 from its first MFMA to its last, and forms the next tile's V at 0 meanwhile.
+            __builtin_amdgcn_s_setprio(2);
+            acc[m][0] = mfma16(a[0][0], v[0][0], acc[m][0]);
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int k = (s == 0 ? 1 : 0); k < 4; ++k) acc[m][k] = mfma16(a[k][s], v[k][s], acc[m][k]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
+// 1x1 GEMM in the same column mapping: acc[m][o] += W[own 16 channels][128] * x(P(m) + 2 o)
+__device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xrow, gv4f_ptr wl, v4f a_first) {
+    v4f a_nxt = a_first, b[MW][2];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) b[m][o] = *(const v4f*)(xrow + (4 * m + 2 * o) * LDS_S);
+    for (int g = 0; g < KGC; ++g) {
+        const v4f a = a_nxt;
+        const int gn = (g + 1 < KGC) ? g + 1 : g;
+        a_nxt = wl[(size_t)gn * (KGC * 64)];
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            __builtin_amdgcn_s_setprio(2);                      // turn-taking with the SIMD's other wave, as in conv_gemm_wino
+            acc[m][0] = mfma16(a[0], b[m][0][0], acc[m][0]);
+            __builtin_amdgcn_s_setprio(3);
+            acc[m][1] = mfma16(a[0], b[m][1][0], acc[m][1]);
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+#pragma unroll
+                for (int o = 0; o < 2; ++o) acc[m][o] = mfma16(a[s], b[m][o][s], acc[m][o]);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) b[m][o] = *(const v4f*)(xrow + (4 * m + 2 * o) * LDS_S + gn * 16);
+        }
+    }
+}
+
 // 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.  Output unit
 // u = 2*pt + n (13 position tiles x 2 channel tiles) is owned by wave u % NWAVE: every wave has ONE channel tile
 // n = wave & 1 (so one weight fragment per k-group, no selects) and the position tiles pt = (wave >> 1) mod 4
@@ -169,6 +276,7 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
 // ------------------------------------------------------------------------------------------------
 // segment kernel: one workgroup = one read, layers [l_begin, l_end) with the read resident in LDS
 // ------------------------------------------------------------------------------------------------
+template <bool WINO>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
     __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
@@ -188,13 +296,28 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     for (int n = 0; n < NT; ++n) chb[n] = (cq * NT + n) * 16 + kk * 4;
 
     STAMP(0);
+    // Winograd column mapping of this lane (used by the WINO instantiation on its dilation-2 layers)
+    [[maybe_unused]] const int wP0 = wino_base(lane);
+    [[maybe_unused]] const int wlim = ((lane >> 2) & 1) ? MPOS : WHB;      // positions this lane's tiling owns: p < wlim
+    [[maybe_unused]] const int chw = wave * 16 + kk * 4;
+    auto dil_of = [&](int l) { return (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final); };
+    auto wino_layer = [&](int l) { return WINO && l > 0; };
     // first conv's first weight fragments: in flight during the whole prologue
-    v4f pre_conv[NT];
-    {
-        gv4f_ptr w0 = (gv4f_ptr)(a.wl + (size_t)a.l_begin * LAYER_STRIDE + W_OFF) + (cq * NT) * 64 + lane;
+    constexpr int NPRE = WINO ? 4 : NT;
+    v4f pre_conv[NPRE];
+    auto first_frags = [&](int l, v4f (&dst)[NPRE]) {
+        const float* blk = a.wl + (size_t)l * LAYER_STRIDE;
+        if (wino_layer(l)) {
+            gv4f_ptr w0 = (gv4f_ptr)(blk + WW_OFF) + wave * 64 + lane;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) pre_conv[n] = w0[n * 64];
-    }
+            for (int k = 0; k < NPRE; ++k) dst[k] = w0[(size_t)k * KGC * (KGC * 64)];
+        } else {
+            gv4f_ptr w0 = (gv4f_ptr)(blk + W_OFF) + (cq * NT) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dst[n] = w0[n * 64];
+        }
+    };
+    first_frags(a.l_begin, pre_conv);
     for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
     for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
         const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
@@ -267,23 +390,44 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     STAMP(1);
     if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
 
-    for (int l = a.l_begin; l < a.l_end; ++l) {
+    // per-layer prologue/tail shared by both forms
+    v4f pre_next[NPRE], wbot[KGC];
+    auto layer_tail = [&](int l, const float* lc) {
+        [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+        __syncthreads();
+        STAMP(sb + 6);
+        if (a.tap && a.tap_layer == l + 1) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+        if (a.has_hw)
+            bottleneck(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave,
+                       lane);
+        STAMP(sb + 7);
+#pragma unroll
+        for (int n = 0; n < NPRE; ++n) pre_conv[n] = pre_next[n];
+    };
+
+    // ---- direct form: wave = (channel quarter, position half), 3-tap implicit GEMM
+    auto direct_layer = [&](int l) {
         const float* wblk = a.wl + (size_t)l * LAYER_STRIDE;
         const float* lc = cst + (l - a.l_begin) * CST_FLOATS;
         const bool residual = (a.res_mask >> l) & 1u;
         const int kg = (l == 0) ? KG0 : KGC;
-        const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
+        const int dil = dil_of(l);
         gv4f_ptr w_conv = (gv4f_ptr)(wblk + W_OFF) + (cq * NT) * 64 + lane;
         gv4f_ptr w_res = (gv4f_ptr)(wblk + WRES_OFF) + (cq * NT) * 64 + lane;
         gv4f_ptr w_bot = (gv4f_ptr)(wblk + WBOT_OFF) + lane;
+        [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         // first fragments of the later GEMM stages of this layer and of the next conv: loaded now, used after
         // the conv GEMM, so their L2 latency is never exposed
-        v4f pre_res[NT], pre_next[NT];
+        if (l + 1 < a.l_end) first_frags(l + 1, pre_next);
+        // x_in of a residual layer is the layer input BEFORE the pool add (model.py:732): for the first layer of a
+        // pooled segment it is re-read from HBM
+        const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
+        v4f pre_res[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            pre_res[n] = residual ? w_res[n * 64] : splat(0.f);
-            pre_next[n] = (l + 1 < a.l_end) ? w_conv[(size_t)(LAYER_STRIDE / 4) + n * 64] : splat(0.f);
-        }
+        for (int n = 0; n < NT; ++n) pre_res[n] = residual ? w_res[n * 64] : splat(0.f);
+        v4f pre_dir[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pre_dir[n] = pre_conv[n];
 
         v4f acc[MTW][NT];
         {
@@ -295,14 +439,12 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = bias[n];
         }
-        [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         STAMP(sb + 0);
-        conv_gemm(acc, xs, w_conv, pre_conv, kg, 3, dil, lane, m_base, cnt);
+        conv_gemm(acc, xs, w_conv, pre_dir, kg, 3, dil, lane, m_base, cnt);
         STAMP(sb + 1);
         // this wave's eight bottleneck weight fragments of the layer: issued now, consumed after the epilogue
         // (and the residual GEMM), so the ~1.5k-cycle loaded-L2 latency is off the critical path
         // (for residual layers they are issued after the residual GEMM instead, to keep 32 registers free in it)
-        v4f wbot[KGC];
         if (a.has_hw && !residual) {
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
@@ -334,7 +476,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             v4f bres[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) bres[n] = *(const v4f*)(lc + CST_BRES + chb[n]);
-            const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
             if (!from_global) {
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
@@ -389,15 +530,108 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
                 }
             }
         }
-        __syncthreads();
-        STAMP(sb + 6);
-        if (a.tap && a.tap_layer == l + 1) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
-        if (a.has_hw)
-            bottleneck(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave,
-                       lane);
-        STAMP(sb + 7);
+        layer_tail(l, lc);
+    };
+
+    // ---- Winograd form (dilation-2 layers of the WINO instantiation): wave = one 16-channel tile, all positions
+    [[maybe_unused]] auto wino_layer_body = [&](int l) {
+        if constexpr (WINO) {
+        const float* wblk = a.wl + (size_t)l * LAYER_STRIDE;
+        const float* lc = cst + (l - a.l_begin) * CST_FLOATS;
+        const bool residual = (a.res_mask >> l) & 1u;
+        gv4f_ptr w_bot = (gv4f_ptr)(wblk + WBOT_OFF) + lane;
+        [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+        const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
+        gv4f_ptr w_w = (gv4f_ptr)(wblk + WW_OFF) + wave * 64 + lane;
+        gv4f_ptr w_r1 = (gv4f_ptr)(wblk + WRES_OFF) + wave * 64 + lane;
+        float* xw = xs + (HALO + wP0) * LDS_S;          // row of x(P(0)) (channel 0)
+        v4f out[MW][2], pre_r1;
+        int wp = wP0;
+        float* xq;
+        {
+            v4f acc[MW][4];
+            const v4f bias = *(const v4f*)(lc + CST_BIAS + chw);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) pre_conv[n] = pre_next[n];
+            for (int m = 0; m < MW; ++m) { acc[m][0] = splat(0.f); acc[m][1] = bias; acc[m][2] = splat(0.f); acc[m][3] = splat(0.f); }
+            STAMP(sb + 0);
+            conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w, pre_conv);
+            STAMP(sb + 1);
+            asm volatile("" : "+v"(wp));       // keeps everything derived from it (addresses, masks) out of the GEMM's live set
+            xq = xs + (HALO + wp) * LDS_S;
+            // the accumulators fill the register file during the GEMM: the later stages' first fragments are
+            // requested only now (the epilogue and the barriers cover their latency)
+            pre_r1 = residual ? w_r1[0] : splat(0.f);
+            if (l + 1 < a.l_end) first_frags(l + 1, pre_next);
+            if (a.has_hw && !residual) {
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
+            }
+            // output transform, then ReLU and the folded BatchNorm (model.py:749-751); positions >= L stay zero
+            const v4f sc = *(const v4f*)(lc + CST_SCALE + chw), sh = *(const v4f*)(lc + CST_SHIFT + chw);
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const v4f y0 = acc[m][0] + acc[m][1] + acc[m][2], y1 = acc[m][1] - acc[m][2] - acc[m][3];
+                const int p = wp + 4 * m;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    out[m][0][j] = (p < L) ? relu1(y0[j]) * sc[j] + sh[j] : 0.f;
+                    out[m][1][j] = (p + 2 < L) ? relu1(y1[j]) * sc[j] + sh[j] : 0.f;
+                }
+            }
+        }
+        STAMP(sb + 2);
+        __syncthreads();                                // every wave has finished reading the layer input
+        STAMP(sb + 3);
+        if (residual) {
+            const v4f bres = *(const v4f*)(lc + CST_BRES + chw);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int p = wp + 4 * m + 2 * o;
+                    if (p < wlim) {
+                        v4f* cell = (v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw);
+                        const v4f old = from_global ? ((p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chw) : splat(0.f)) : *cell;
+                        *cell = out[m][o];
+                        out[m][o] = old + bres;
+                    }
+                }
+            __syncthreads();
+            STAMP(sb + 4);
+            gemm1x1_wino(out, xq + kk * 4, w_r1, pre_r1);
+            STAMP(sb + 5);
+            if (a.has_hw) {
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int p = wp + 4 * m + 2 * o;
+                    if (p < wlim) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = (p < L) ? out[m][o] : splat(0.f);
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int p = wp + 4 * m + 2 * o;
+                    if (p < wlim) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = out[m][o];
+                }
+        }
+        layer_tail(l, lc);
+        }
+    };
+
+    if constexpr (WINO) {
+        // host contract (launch_segment): every layer after the network's first has dilation 2
+        int l = a.l_begin;
+        if (l == 0) { direct_layer(0); l = 1; }
+        for (; l < a.l_end; ++l) wino_layer_body(l);
+    } else {
+        for (int l = a.l_begin; l < a.l_end; ++l) direct_layer(l);
     }
     STAMP(62);
     copy_out(xs, yrow, L, tid);
@@ -405,7 +639,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 }
 
 void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s) {
-    hipLaunchKernelGGL(segment_kernel, dim3((unsigned)(n_sites * a.R)), dim3(SEG_THREADS), 0, s, a);
+    if (a.wino) hipLaunchKernelGGL(segment_kernel<true>, dim3((unsigned)(n_sites * a.R)), dim3(SEG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(segment_kernel<false>, dim3((unsigned)(n_sites * a.R)), dim3(SEG_THREADS), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,9 +38,11 @@ def main(argv=None) -> int:
     cfg = DanConfig.from_args(args)                           # rejects unsupported model options loudly
     if args.precision not in ("fp32", "bf16x3", "bf16"):
         raise SystemExit("--precision must be fp32, bf16x3 or bf16")
-    if args.precision != "fp32":
-        import dataclasses
-        cfg = dataclasses.replace(cfg, precision=("fp32", "bf16x3", "bf16").index(args.precision))
+    if args.conv_algo not in ("auto", "direct", "winograd"):
+        raise SystemExit("--conv-algo must be auto, direct or winograd")
+    import dataclasses
+    cfg = dataclasses.replace(cfg, precision=("fp32", "bf16x3", "bf16").index(args.precision),
+                              conv_algo=("auto", "direct", "winograd").index(args.conv_algo))
     shard_i, shard_n = parse_shard(args.shard)
     if args.save_vcf_records:
         assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"

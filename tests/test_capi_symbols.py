@@ -51,11 +51,18 @@ def test_abi_version(lib):
 
 
 def test_config_struct_layout():
-    # 20 x 4-byte fields, no padding: must match struct dan_config in the header
-    assert ctypes.sizeof(capi.DanCConfig) == 4 * 20
+    # 21 x 4-byte fields, no padding: must match struct dan_config in the header
+    assert ctypes.sizeof(capi.DanCConfig) == 4 * 21
     cc = capi.c_config(production_config(reads=64), device_id=3)
     assert (cc.reads, cc.length, cc.layers, cc.device_id) == (64, 201, 7, 3)
     assert cc.pool_layers_mask == 1 << 2 and list(cc.fc_sizes) == [1024, 256]
+
+
+def test_header_struct_fields_match_binding():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct dan_config \{(.*?)\} dan_config;", text, flags=re.S).group(1)
+    names = re.findall(r"u?int32_t\s+([a-z_]+)(?:\[\d+\])?\s*;", body)
+    assert names == [f[0] for f in capi.DanCConfig._fields_]
 
 
 def test_create_rejects_bad_config_without_touching_the_gpu(lib):
@@ -65,6 +72,9 @@ def test_create_rejects_bad_config_without_touching_the_gpu(lib):
     assert lib.dan_create(ctypes.byref(cc), ctypes.byref(h)) == -1
     assert b"length" in lib.dan_last_error(None)
     assert not h.value
+    cc = capi.c_config(DanConfig(reads=8, dil_mid=3, conv_algo=2), 0)      # Winograd form needs dilation 2
+    assert lib.dan_create(ctypes.byref(cc), ctypes.byref(h)) == -1
+    assert b"dilation 2" in lib.dan_last_error(None)
 
 
 def test_no_gpu_means_loud_failure(lib):

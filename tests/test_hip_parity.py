@@ -17,9 +17,15 @@ SCORE_ATOL = 1e-4
 TAP_RTOL = 1e-4
 
 
-def cfg_from(spec) -> DanConfig:
+def cfg_from(spec, **over) -> DanConfig:
     keys = DanConfig.__dataclass_fields__.keys()
-    return DanConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in keys})
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in keys}
+    kw.update(over)
+    return DanConfig(**kw)
+
+
+# conv_algo 0 = auto (Winograd F(2,3) on the dilation-2 layers where the configuration allows it), 1 = direct 3-tap GEMM
+ALGOS = [0, 1]
 
 
 def close(got, ref, tol, what):
@@ -28,10 +34,11 @@ def close(got, ref, tol, what):
     assert err <= tol * scale, "%s: max abs err %.3g > %.3g" % (what, err, tol * scale)
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("case", model_cases())
-def test_golden_outputs(case):
+def test_golden_outputs(case, algo):
     spec, w, inp, out = load_case(case)
-    cfg = cfg_from(spec)
+    cfg = cfg_from(spec, conv_algo=algo)
     net = DanNet(cfg).load_state_dict(w)
     got = net.forward_u8(*input_tuple(inp), aux=True)
     for k in ("vt_prob", "bp"):
@@ -50,10 +57,11 @@ def test_golden_outputs(case):
     net.close()
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("layer", [2, 7])
-def test_golden_layer_taps(layer):
+def test_golden_layer_taps(layer, algo):
     spec, w, inp, out = load_case("dan_small")
-    cfg = cfg_from(spec)
+    cfg = cfg_from(spec, conv_algo=algo)
     net = DanNet(cfg).load_state_dict(w)
     net.handle.set_tap(layer)
     net.forward_u8(*input_tuple(inp))
@@ -177,3 +185,51 @@ def test_other_window_lengths(length):
     for k in ("vt_logits", "bin_logits", "vb"):
         close(got[k], want[k], TAP_RTOL, k)
     close(got["vt_prob"], want["vt_prob"], SCORE_ATOL, "vt_prob")
+
+
+WINO_STRUCTURES = {
+    # the second segment starts ON a residual layer: x_in is re-read from HBM in the Winograd column mapping
+    "residual_at_segment_start": dict(layers=5, residual_start=3, pool_layers=(2,)),
+    "two_pools_residual_2": dict(layers=6, residual_start=2, pool_layers=(1, 3)),
+    "narrow_final_layer": dict(layers=4, c_final=48, residual_start=3),
+    "no_highway_no_bn": dict(layers=4, bottleneck=0, use_bn=False, residual_start=0, pool_layers=()),
+    "two_layers": dict(layers=2, residual_start=2, pool_layers=(1,)),
+    "full_width": dict(layers=3, c_init=128, c_final=128, bottleneck=32, residual_start=2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WINO_STRUCTURES))
+def test_winograd_structures_against_oracle_and_direct(name):
+    """Forced Winograd form on structural variants the golden set only holds with other dilations: against the oracle
+    at the parity tolerance, and against the direct form of the same library (same weights, same inputs)."""
+    kw = dict(reads=9, length=201, c_init=40, c_final=40, bottleneck=8, fc_sizes=(32, 16))
+    kw.update(WINO_STRUCTURES[name])
+    cfg_w, cfg_d = DanConfig(conv_algo=2, **kw), DanConfig(conv_algo=1, **kw)
+    assert cfg_w.winograd_applies() and not cfg_d.winograd_applies()
+    sd = random_state_dict(cfg_w, seed=41)
+    batch = synth.make_sites(5, reads=cfg_w.reads, seed=42)
+    want = dan_forward_oracle(sd, cfg_w, *batch.arrays(), taps=True)
+    outs = {}
+    for tag, cfg in (("winograd", cfg_w), ("direct", cfg_d)):
+        net = DanNet(cfg).load_state_dict(sd)
+        net.handle.set_tap(cfg.layers)
+        outs[tag] = got = net.forward_u8(*batch.arrays(), aux=True)
+        B, R, L = batch.reads.shape
+        cpad = net.handle.query("cpad")
+        tap = net.handle.read_buffer("tap", B * R * L * cpad).reshape(B, R, L, cpad)
+        ref = want["conv%d" % cfg.layers]
+        close(np.transpose(tap[..., :ref.shape[1]], (0, 3, 1, 2)), ref, TAP_RTOL, "%s:%s:last conv" % (name, tag))
+        assert np.all(tap[..., ref.shape[1]:] == 0)
+        for k in ("vt_prob", "bp"):
+            close(got[k], want[k], SCORE_ATOL, "%s:%s:%s" % (name, tag, k))
+        for k in ("bin_logits", "vt_logits", "af", "cov", "vb", "vr"):
+            close(got[k], want[k], TAP_RTOL, "%s:%s:%s" % (name, tag, k))
+        net.close()
+    close(outs["winograd"]["vt_prob"], outs["direct"]["vt_prob"].astype(np.float64), 1e-5, name + ": winograd vs direct")
+
+
+def test_winograd_needs_dilation_two():
+    with pytest.raises(RuntimeError, match="dilation 2"):
+        DanNet(DanConfig(reads=8, dil_mid=1, conv_algo=2))
+    net = DanNet(DanConfig(reads=8, dil_mid=1, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8)))   # auto -> direct
+    net.close()

@@ -13,6 +13,7 @@ using namespace dan;
 int main(int argc, char** argv) {
     const int l_begin = argc > 2 ? atoi(argv[1]) : 2, l_end = argc > 2 ? atoi(argv[2]) : 7;
     const int precision = argc > 3 ? atoi(argv[3]) : 0;
+    const int wino = argc > 4 ? atoi(argv[4]) : 0;
     const int R = 64, L = 201, sites = 64, layers = 7, nwg = sites * R;
     std::vector<float> wl((size_t)layers * LAYER_STRIDE);
     srand(1);
@@ -42,7 +43,7 @@ int main(int argc, char** argv) {
     a.res_mask = 0x70; a.has_hw = 1; a.R = R; a.L = L;
     a.reads = a.qual = a.strand = a.ref = a.ref_mask = a.var_mask = d_u8;
     a.emb = d_emb; a.pe = d_pe; a.y = d_y; a.pool = l_begin ? d_pool : nullptr; a.h = d_h; a.h_layer_stride = (long long)hls;
-    a.tap = nullptr; a.tap_layer = -1;
+    a.tap = nullptr; a.tap_layer = -1; a.wino = wino;
     char* d_wl16;
     CK(hipMalloc(&d_wl16, (size_t)layers * W16_LAYER_BYTES));
     CK(hipMemset(d_wl16, 0, (size_t)layers * W16_LAYER_BYTES));
