@@ -225,6 +225,10 @@ constexpr int PSTEP = NWAVE / 2;                      // position-tile stride of
 constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
 __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
                                            int wave, int lane) {
+    // everything below is recomputed per call from an opaque copy of the lane index: hoisted out of the layer loop, the
+    // per-tile offsets and 64-bit store addresses would sit in registers through the conv GEMMs (and spill)
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // (not even the lane index is kept)
+    asm volatile("" : "+v"(lane));
     const int pos = lane & 15, kk = lane >> 4;
     const int n = wave & 1, p0 = wave >> 1;
     const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
@@ -303,21 +307,24 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     auto dil_of = [&](int l) { return (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final); };
     auto wino_layer = [&](int l) { return WINO && l > 0; };
     // first conv's first weight fragments: in flight during the whole prologue
-    constexpr int NPRE = WINO ? 4 : NT;
-    v4f pre_conv[NPRE];
-    auto first_frags = [&](int l, v4f (&dst)[NPRE]) {
+    // (named members, returned by value: arrays captured by reference in the layer lambdas end up in scratch memory)
+    struct Frags { v4f f0, f1, f2, f3; };
+    auto first_frags = [&](int l) -> Frags {
         const float* blk = a.wl + (size_t)l * LAYER_STRIDE;
+        Frags r;
         if (wino_layer(l)) {
             gv4f_ptr w0 = (gv4f_ptr)(blk + WW_OFF) + wave * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < NPRE; ++k) dst[k] = w0[(size_t)k * KGC * (KGC * 64)];
+            constexpr size_t KS = (size_t)KGC * (KGC * 64);
+            r.f0 = w0[0]; r.f1 = w0[KS]; r.f2 = w0[2 * KS]; r.f3 = w0[3 * KS];
         } else {
             gv4f_ptr w0 = (gv4f_ptr)(blk + W_OFF) + (cq * NT) * 64 + lane;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) dst[n] = w0[n * 64];
+            r.f0 = w0[0]; r.f1 = w0[64]; r.f2 = r.f0; r.f3 = r.f1;
         }
+        return r;
     };
-    first_frags(a.l_begin, pre_conv);
+    // (a resumed segment of the WINO instantiation asks for them after its 52-load prologue instead: no registers to spare)
+    Frags pre_conv = {}, pre_next = {};
+    if (!WINO || a.l_begin == 0) pre_conv = first_frags(a.l_begin);
     for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
     for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
         const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
@@ -385,24 +392,31 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             const int i = tid + k * SEG_THREADS;
             if (i < n4) *(v4f*)(xs + (HALO + (i >> 5)) * LDS_S + (i & 31) * 4) = vy[k] + vp[k];
         }
+        if (WINO) pre_conv = first_frags(a.l_begin);
     }
     __syncthreads();
     STAMP(1);
     if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
 
     // per-layer prologue/tail shared by both forms
-    v4f pre_next[NPRE], wbot[KGC];
+    v4f wbot[KGC];
     auto layer_tail = [&](int l, const float* lc) {
         [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         __syncthreads();
         STAMP(sb + 6);
-        if (a.tap && a.tap_layer == l + 1) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+        if (a.tap && a.tap_layer == l + 1) {                // (diagnostic path: its addresses must not be hoisted into registers)
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, t);
+        }
+        // WINO instantiation: the next conv's first four weight fragments are requested here, behind the bottleneck GEMM
+        // (any earlier and they sit in registers through the residual GEMM, where there are none to spare)
+        if (WINO && l + 1 < a.l_end) pre_next = first_frags(l + 1);
         if (a.has_hw)
             bottleneck(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave,
                        lane);
         STAMP(sb + 7);
-#pragma unroll
-        for (int n = 0; n < NPRE; ++n) pre_conv[n] = pre_next[n];
+        pre_conv = pre_next;
     };
 
     // ---- direct form: wave = (channel quarter, position half), 3-tap implicit GEMM
@@ -418,16 +432,15 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         // first fragments of the later GEMM stages of this layer and of the next conv: loaded now, used after
         // the conv GEMM, so their L2 latency is never exposed
-        if (l + 1 < a.l_end) first_frags(l + 1, pre_next);
+        if (!WINO && l + 1 < a.l_end) pre_next = first_frags(l + 1);
         // x_in of a residual layer is the layer input BEFORE the pool add (model.py:732): for the first layer of a
         // pooled segment it is re-read from HBM
         const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
         v4f pre_res[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) pre_res[n] = residual ? w_res[n * 64] : splat(0.f);
-        v4f pre_dir[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) pre_dir[n] = pre_conv[n];
+        static_assert(NT == 2, "Frags holds two direct-form fragments");
+        const v4f pre_dir[NT] = {pre_conv.f0, pre_conv.f1};
 
         v4f acc[MTW][NT];
         {
@@ -554,18 +567,11 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 #pragma unroll
             for (int m = 0; m < MW; ++m) { acc[m][0] = splat(0.f); acc[m][1] = bias; acc[m][2] = splat(0.f); acc[m][3] = splat(0.f); }
             STAMP(sb + 0);
-            conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w, pre_conv);
+            const v4f pre_w[4] = {pre_conv.f0, pre_conv.f1, pre_conv.f2, pre_conv.f3};
+            conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w, pre_w);
             STAMP(sb + 1);
             asm volatile("" : "+v"(wp));       // keeps everything derived from it (addresses, masks) out of the GEMM's live set
             xq = xs + (HALO + wp) * LDS_S;
-            // the accumulators fill the register file during the GEMM: the later stages' first fragments are
-            // requested only now (the epilogue and the barriers cover their latency)
-            pre_r1 = residual ? w_r1[0] : splat(0.f);
-            if (l + 1 < a.l_end) first_frags(l + 1, pre_next);
-            if (a.has_hw && !residual) {
-#pragma unroll
-                for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
-            }
             // output transform, then ReLU and the folded BatchNorm (model.py:749-751); positions >= L stay zero
             const v4f sc = *(const v4f*)(lc + CST_SCALE + chw), sh = *(const v4f*)(lc + CST_SHIFT + chw);
 #pragma unroll
@@ -578,6 +584,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
                     out[m][1][j] = (p + 2 < L) ? relu1(y1[j]) * sc[j] + sh[j] : 0.f;
                 }
             }
+        }
+        // the accumulators fill the register file through the GEMM and the output transform: the later stages' first
+        // fragments are requested only now (the barriers, the write-back and the residual GEMM cover their latency)
+        __builtin_amdgcn_sched_barrier(0);
+        pre_r1 = residual ? w_r1[0] : splat(0.f);
+        if (a.has_hw && !residual) {
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
         }
         STAMP(sb + 2);
         __syncthreads();                                // every wave has finished reading the layer input

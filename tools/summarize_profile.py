@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 outputs of tools/profile_round.sh into the small files kept under profiles/.
+
+    python tools/summarize_profile.py r01   # reads gpurun_out/prof_r01/, writes profiles/r01_*
+
+  * <tag>_kernel_stats_default_bench.csv   rocprofv3 --kernel-trace --stats summary (verbatim) of the default bench command,
+                                          plus the segment kernel split by template instantiation / segment
+  * <tag>_bench_line_under_rocprof.json    the JSON line bench.py printed in that same run
+  * <tag>_traffic.json                     FETCH_SIZE / WRITE_SIZE per kernel (KB as reported), corrected bytes per launch
+  * <tag>_pmc_sq_summary.csv               SQ counters summed over dispatches per kernel
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    if not hits:
+        raise SystemExit("no file matches " + pattern)
+    return hits[-1]
+
+
+def short(name):
+    m = re.match(r"(?:void )?([A-Za-z_:0-9]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name
+
+
+def counters(path):
+    """{kernel: {counter: [values per dispatch]}} -- a dispatch's rows per counter are summed (one row per XCD/SE)."""
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            per[short(row["Kernel_Name"])][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return {k: {c: list(d.values()) for c, d in cs.items()} for k, cs in per.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+
+    # ---- kernel trace
+    stats = one(os.path.join(src, "kt", "**", "*_kernel_stats.csv"))
+    trace = one(os.path.join(src, "kt", "**", "*_kernel_trace.csv"))
+    seg = defaultdict(list)
+    with open(trace) as f:
+        for row in csv.DictReader(f):
+            if "segment_kernel" in row["Kernel_Name"]:
+                seg[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open(os.path.join(dst, tag + "_kernel_stats_default_bench.csv"), "w") as out:
+        out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (kernel_stats.csv, verbatim)\n")
+        out.write(open(stats).read())
+        out.write("# segment kernel launches alternate between the two layer segments of a chunk (layers 1-2, layers 3-7):\n")
+        out.write("# kernel,launches,avg_ns_all,avg_ns_even_launches(segment 1),avg_ns_odd_launches(segment 2)\n")
+        for k, d in seg.items():
+            ev, od = d[0::2], d[1::2]
+            out.write("# %s,%d,%.0f,%.0f,%.0f\n" % (k, len(d), sum(d) / len(d), sum(ev) / max(len(ev), 1), sum(od) / max(len(od), 1)))
+    line = [l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1]
+    with open(os.path.join(dst, tag + "_bench_line_under_rocprof.json"), "w") as out:
+        out.write(line)
+
+    # ---- HBM traffic
+    traffic = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
+                          "--sites 4096 --steps 1 --warmup 0 --no-cpu-baseline   (default chunk = 128 sites, 2 segment launches per chunk)",
+               "units": "rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at "
+                        "64 B for wide coalesced streams, MI355X_MICROARCH.md section HBM); WRITE_SIZE is exact for 16-B-per-lane stores",
+               "per_kernel": {}}
+    seg_bytes = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        per = counters(one(os.path.join(src, c, "**", "*_counter_collection.csv")))
+        traffic["per_kernel"][c] = {}
+        for k, cs in per.items():
+            if not k.startswith("dan::"):
+                continue
+            v = cs[c]
+            traffic["per_kernel"][c][k] = {"dispatches": len(v), "mean_KB": sum(v) / len(v), "min_KB": min(v), "max_KB": max(v)}
+            if "segment_kernel" in k:
+                seg_bytes[c] = sum(v) / len(v) * 1024.0
+    fetch = 2.0 * seg_bytes["FETCH_SIZE"]
+    traffic["segment_kernel_bytes_per_launch"] = {"fetch_corrected": fetch, "write": seg_bytes["WRITE_SIZE"],
+                                                  "total": fetch + seg_bytes["WRITE_SIZE"]}
+    R, L, S = 64, 201, 128
+    y = S * R * L * 128 * 4
+    algo = (S * (3 * R * L + 3 * L) + 3 * y + 7 * S * R * L * 32 * 4 + S * L * 128 * 4) / 2.0
+    traffic["segment_kernel_algorithmic_bytes_per_launch"] = {
+        "note": "chunk of 128 sites x 64 reads x 201: uint8 inputs + y2 write + y2 read + pool read + y7 write + bottleneck outputs "
+                "h 7 x 210.8 MB, averaged over the two launches of a chunk", "total": algo}
+    with open(os.path.join(dst, tag + "_traffic.json"), "w") as out:
+        json.dump(traffic, out, indent=1)
+
+    # ---- SQ counters
+    rows = defaultdict(dict)
+    disp = {}
+    for d in ("SQ", "SQ2"):
+        per = counters(one(os.path.join(src, d, "**", "*_counter_collection.csv")))
+        for k, cs in per.items():
+            if k.startswith("dan::"):
+                for c, v in cs.items():
+                    rows[k][c] = sum(v)
+                    disp[k] = len(v)
+    names = sorted({c for r in rows.values() for c in r})
+    with open(os.path.join(dst, tag + "_pmc_sq_summary.csv"), "w") as out:
+        out.write("# rocprofv3 --pmc <SQ counters, two passes> -- python3 bench.py --sites 4096 --steps 1 --warmup 0 --no-cpu-baseline ; sums over dispatches\n")
+        out.write("kernel,dispatches," + ",".join(names) + "\n")
+        for k, r in rows.items():
+            out.write("%s,%d,%s\n" % (k, disp[k], ",".join("%.6g" % r.get(c, float("nan")) for c in names)))
+        for k, r in rows.items():
+            if "segment_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in r and "SQ_BUSY_CU_CYCLES" in r:
+                out.write("# %s: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) = %.4f\n"
+                          % (k, r["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * r["SQ_BUSY_CU_CYCLES"])))
+    print("wrote profiles/%s_*" % tag)
+
+
+if __name__ == "__main__":
+    main()
