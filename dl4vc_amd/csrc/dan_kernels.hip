@@ -173,17 +173,15 @@ __device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* x
                 xa = *(const v4f*)(xn); xb = *(const v4f*)(xn + 2 * LDS_S);
                 xc = *(const v4f*)(xn + 4 * LDS_S); xd = *(const v4f*)(xn + 6 * LDS_S);
             }
-            // Take turns with the SIMD's other wave, one tile each: the arbiter serves the highest s_setprio first and
-            // the OLDER wave on a tie, so without this the older wave keeps the matrix pipe to itself, the younger one
-            // only fills its gaps and then runs alone, exposing its own VALU/LDS gaps.  A wave asks at priority 2,
-            // holds the pipe at 3 from its first MFMA to its last, and forms the next tile's V at 0 meanwhile.
-            __builtin_amdgcn_s_setprio(2);
-            acc[m][0] = mfma16(a[0][0], v[0][0], acc[m][0]);
+            // MFMAs at s_setprio 3, the VALU/LDS stretch that forms the next V at 0: the arbiter then serves the other
+            // wave's MFMAs ahead of this wave's VALU stream (by default the OLDER wave's instructions of either kind come
+            // first, and its VALU batches stall the younger wave's MFMA issue).  tools/ubench/wino_loop.hip: 37.6 -> 36.4
+            // cycles per MFMA at the SIMD.
             __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int k = (s == 0 ? 1 : 0); k < 4; ++k) acc[m][k] = mfma16(a[k][s], v[k][s], acc[m][k]);
+                for (int k = 0; k < 4; ++k) acc[m][k] = mfma16(a[k][s], v[k][s], acc[m][k]);
             __builtin_amdgcn_s_setprio(0);
         }
     }
@@ -202,12 +200,9 @@ __device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xro
         a_nxt = wl[(size_t)gn * (KGC * 64)];
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-            __builtin_amdgcn_s_setprio(2);                      // turn-taking with the SIMD's other wave, as in conv_gemm_wino
-            acc[m][0] = mfma16(a[0], b[m][0][0], acc[m][0]);
-            __builtin_amdgcn_s_setprio(3);
-            acc[m][1] = mfma16(a[0], b[m][1][0], acc[m][1]);
+            __builtin_amdgcn_s_setprio(3);                      // MFMAs ahead of the other wave's LDS/VALU work, as in conv_gemm_wino
 #pragma unroll
-            for (int s = 1; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) acc[m][o] = mfma16(a[s], b[m][o][s], acc[m][o]);
             __builtin_amdgcn_s_setprio(0);

@@ -79,6 +79,24 @@ int main(int argc, char** argv) {
                med(sb + 1, sb + 2, -1), med(sb + 2, sb + 3, -1), med(sb + 3, sb + 4, -1), med(sb + 4, sb + 5, -1),
                med(((a.res_mask >> l) & 1) ? sb + 5 : sb + 3, sb + 6, -1), med(sb + 6, sb + 7, -1), med(sb + 6, sb + 7, 0), med(sb + 6, sb + 7, 3));
     }
+    {   // per-wave view of the second layer of the segment: conv start relative to wave 0's, conv length, barrier wait
+        const int l = l_begin + 1 < l_end ? l_begin + 1 : l_begin, sb = 2 + (l - l_begin) * 8;
+        printf("L%d per wave (start vs wave 0 | conv | epilogue+barrier wait):", l + 1);
+        for (int w = 0; w < NWAVE; ++w) {
+            std::vector<long long> off, len, wait;
+            for (int wg = 0; wg < nwg; ++wg) {
+                const unsigned long long* s0 = &st[((size_t)wg * NWAVE + 0) * NSTAMP];
+                const unsigned long long* sw = &st[((size_t)wg * NWAVE + w) * NSTAMP];
+                if (s0[sb] && sw[sb] && sw[sb + 1] && sw[sb + 3]) {
+                    off.push_back((long long)(sw[sb] - s0[sb])); len.push_back((long long)(sw[sb + 1] - sw[sb]));
+                    wait.push_back((long long)(sw[sb + 3] - sw[sb + 1]));
+                }
+            }
+            std::sort(off.begin(), off.end()); std::sort(len.begin(), len.end()); std::sort(wait.begin(), wait.end());
+            if (!off.empty()) printf("  w%d %lld|%lld|%lld", w, off[off.size() / 2], len[len.size() / 2], wait[wait.size() / 2]);
+        }
+        printf("\n");
+    }
     printf("copy_out                    %8lld\n", med(62, 63, -1));
     printf("total                       %8lld\n", med(0, 63, -1));
     return 0;

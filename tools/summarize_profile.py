@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)      # gpurun merges runs: newest wins
     if not hits:
         raise SystemExit("no file matches " + pattern)
     return hits[-1]

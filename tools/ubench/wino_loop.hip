@@ -34,9 +34,6 @@ __global__ __launch_bounds__(SEG_THREADS, 2) void k(const float* wl, float* out,
         for (int m = 0; m < MW; ++m) for (int q = 0; q < 4; ++q) acc[m][q] = splat(0.f);
         for (int q = 0; q < 4; ++q) pre[q] = w_w[(size_t)q * KGC * (KGC * 64)];
         const float* xrow = xs + (HALO + wP0 - 2) * LDS_S + kk * 4;
-#if defined(PRIO_TEST) && PRIO_TEST == 1
-        if (wave >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
         t0 = __builtin_amdgcn_s_memtime();
         for (int it = 0; it < iters; ++it) conv_gemm_wino(acc, xrow, w_w, pre);
         t1 = __builtin_amdgcn_s_memtime();
