@@ -216,10 +216,13 @@ __device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xro
 // u = 2*pt + n (13 position tiles x 2 channel tiles) is owned by wave u % NWAVE: every wave has ONE channel tile
 // n = wave & 1 (so one weight fragment per k-group, no selects) and the position tiles pt = (wave >> 1) mod 4
 // -- 4/4/3/3/3/3/3/3 units, i.e. 7/7/6/6 per SIMD.  All eight weight fragments are preloaded by the caller (wf).
-constexpr int PSTEP = NWAVE / 2;                      // position-tile stride of one wave
-constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
+// NW = participating waves: all 8 (standalone stage), or only the 4 OLDER waves (0..3, one per SIMD) when the GEMM is
+// deferred into the next layer's conv stage (see the Winograd layer body).
+template <int NW>
 __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
                                            int wave, int lane) {
+    constexpr int PSTEP = NW / 2;                         // position-tile stride of one wave
+    constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
     // everything below is recomputed per call from an opaque copy of the lane index: hoisted out of the layer loop, the
     // per-tile offsets and 64-bit store addresses would sit in registers through the conv GEMMs (and spill)
     lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // (not even the lane index is kept)
@@ -407,9 +410,13 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         // WINO instantiation: the next conv's first four weight fragments are requested here, behind the bottleneck GEMM
         // (any earlier and they sit in registers through the residual GEMM, where there are none to spare)
         if (WINO && l + 1 < a.l_end) pre_next = first_frags(l + 1);
-        if (a.has_hw)
-            bottleneck(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave,
-                       lane);
+        // WINO instantiation, not the segment's last layer: the bottleneck GEMM of this layer is deferred into the next
+        // layer's conv stage, where the four older waves run it on the same LDS-resident input while the younger wave of
+        // each SIMD is still in its conv GEMM (the arbiter serves the older wave first, so it finishes the conv early and
+        // would only wait at the barrier)
+        if (a.has_hw && !(WINO && l + 1 < a.l_end))
+            bottleneck<NWAVE>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L,
+                              wave, lane);
         STAMP(sb + 7);
         pre_conv = pre_next;
     };
@@ -453,7 +460,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         // this wave's eight bottleneck weight fragments of the layer: issued now, consumed after the epilogue
         // (and the residual GEMM), so the ~1.5k-cycle loaded-L2 latency is off the critical path
         // (for residual layers they are issued after the residual GEMM instead, to keep 32 registers free in it)
-        if (a.has_hw && !residual) {
+        const bool bot_here = a.has_hw && !(WINO && l + 1 < a.l_end);     // else deferred into the next layer's conv stage
+        if (bot_here && !residual) {
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
         }
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             STAMP(sb + 4);
             conv_gemm(acc, xs, w_res, pre_res, KGC, 1, 0, lane, m_base, cnt);
             STAMP(sb + 5);
-            if (a.has_hw) {
+            if (bot_here) {
 #pragma unroll
                 for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
             }
@@ -584,7 +592,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         // fragments are requested only now (the barriers, the write-back and the residual GEMM cover their latency)
         __builtin_amdgcn_sched_barrier(0);
         pre_r1 = residual ? w_r1[0] : splat(0.f);
-        if (a.has_hw && !residual) {
+        // the previous layer's bottleneck GEMM (deferred by its layer_tail): the LDS image is still that layer's output
+        if (a.has_hw && l > a.l_begin && wave < NWAVE / 2) {
+            gv4f_ptr w_bp = (gv4f_ptr)(wblk - LAYER_STRIDE + WBOT_OFF) + lane;
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) wbot[g] = w_bp[(g * 2 + (wave & 1)) * 64];
+            bottleneck<NWAVE / 2>(xs, wbot, lc - CST_FLOATS + CST_BBOT,
+                                  a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+        }
+        const bool bot_here = a.has_hw && !(l + 1 < a.l_end);
+        if (bot_here && !residual) {
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
         }
@@ -609,7 +626,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             STAMP(sb + 4);
             gemm1x1_wino(out, xq + kk * 4, w_r1, pre_r1);
             STAMP(sb + 5);
-            if (a.has_hw) {
+            if (bot_here) {
 #pragma unroll
                 for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
             }
