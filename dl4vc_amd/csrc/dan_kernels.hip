@@ -323,14 +323,17 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     // (a resumed segment of the WINO instantiation asks for them after its 52-load prologue instead: no registers to spare)
     Frags pre_conv = {}, pre_next = {};
     if (!WINO || a.l_begin == 0) pre_conv = first_frags(a.l_begin);
-    for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
-    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
-        const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
-        cst[i] = a.wl[(size_t)(a.l_begin + l) * LAYER_STRIDE + CST_OFF + j];
-    }
-    __syncthreads();
+    auto stage_constants = [&]() {
+        for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
+            const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
+            cst[i] = a.wl[(size_t)(a.l_begin + l) * LAYER_STRIDE + CST_OFF + j];
+        }
+    };
 
     if (a.l_begin == 0) {
+        for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+        stage_constants();
+        __syncthreads();
         // ---- encode (dl4vc/model.py:450-627): canonical 48-channel order
         //      [read emb+pe (20) | ref emb+pe (20) | q*0.01 | strand*0.5 | refmatch | varmatch | lenmask | 0 0 0]
         const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
@@ -385,6 +388,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 #pragma unroll
             for (int k = 0; k < NP; ++k) vp[k] = splat(0.f);
         }
+        // while they fly: zero the rows the read does not cover (halo rows and rows >= L; the 8 pad floats of a row are
+        // never read) and stage the constants
+        for (int i = tid; i < (LDS_ROWS - L) * (LDS_S / 4); i += SEG_THREADS) {
+            const int rr = i / (LDS_S / 4), c4 = i - rr * (LDS_S / 4);
+            const int row = rr < HALO ? rr : rr + L;
+            *(v4f*)(xs + row * LDS_S + c4 * 4) = splat(0.f);
+        }
+        stage_constants();
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int i = tid + k * SEG_THREADS;
