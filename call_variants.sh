@@ -1,7 +1,7 @@
 #!/bin/bash
 # Drop-in for the INFERENCE STAGES of the reference's call_variants.sh (call_variants.sh:99-168): scoring of
-# an existing candidates.hdf with the MI355X-native DAN forward, then sort, genotype thresholds and (when the
-# tools exist) bcftools multi-allele join + bgzip/tabix.  The BAM -> candidates.vcf -> candidates.hdf stages
+# an existing candidates.hdf with the MI355X-native DAN forward, then sort, genotype thresholds, multi-allele join and
+# bgzip/tabix (with bcftools/htslib when installed, else in process: dl4vc_amd/vcfpost.py).  The BAM -> candidates.vcf -> candidates.hdf stages
 # (pysam pileup, reference call_variants.sh:76-97) are CPU pre-processing outside this implementation: run
 # them with the reference's tools, or pass an existing OUTDIR that already holds candidates.{vcf,hdf}.
 set -e
@@ -46,5 +46,8 @@ if command -v bcftools >/dev/null 2>&1; then
   tabix -p vcf "$OUTDIR/called_variants.vcf.gz"
   echo "Called variants in $OUTDIR/called_variants.vcf.gz"
 else
-  echo "bcftools not found: stopping at $OUTDIR/model_test_sorted_thres.vcf"
+  # no bcftools / bgzip / tabix on this machine: the in-process restatement of the same five commands
+  python "$SCRIPTDIR/tools/finish_calls.py" --input_file "$OUTDIR/model_test_sorted_thres.vcf" \
+      --joined_file "$OUTDIR/model_test_sorted_thres-join.vcf" --output_gz "$OUTDIR/called_variants.vcf.gz"
+  echo "Called variants in $OUTDIR/called_variants.vcf.gz (joined and indexed in process: bcftools not found)"
 fi
