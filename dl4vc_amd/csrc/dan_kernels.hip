@@ -409,7 +409,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 
     // per-layer prologue/tail shared by both forms
     v4f wbot[KGC];
-    auto layer_tail = [&](int l, const float* lc) {
+    auto layer_tail = [&](int l, const float* lc, bool late_prefetch) {
         [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         __syncthreads();
         STAMP(sb + 6);
@@ -418,9 +418,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             asm volatile("" : "+v"(t));
             copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, t);
         }
-        // WINO instantiation: the next conv's first four weight fragments are requested here, behind the bottleneck GEMM
-        // (any earlier and they sit in registers through the residual GEMM, where there are none to spare)
-        if (WINO && l + 1 < a.l_end) pre_next = first_frags(l + 1);
+        // WINO instantiation, direct first layer: the next conv's first four weight fragments are requested here (its
+        // Winograd layers request them after their output transform / residual GEMM)
+        if (WINO && late_prefetch && l + 1 < a.l_end) pre_next = first_frags(l + 1);
         // WINO instantiation, not the segment's last layer: the bottleneck GEMM of this layer is deferred into the next
         // layer's conv stage, where the four older waves run it on the same LDS-resident input while the younger wave of
         // each SIMD is still in its conv GEMM (the arbiter serves the older wave first, so it finishes the conv early and
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
                 }
             }
         }
-        layer_tail(l, lc);
+        layer_tail(l, lc, true);
     };
 
     // ---- Winograd form (dilation-2 layers of the WINO instantiation): wave = one 16-channel tile, all positions
@@ -603,6 +603,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         // fragments are requested only now (the barriers, the write-back and the residual GEMM cover their latency)
         __builtin_amdgcn_sched_barrier(0);
         pre_r1 = residual ? w_r1[0] : splat(0.f);
+        if (!residual && l + 1 < a.l_end) pre_next = first_frags(l + 1);      // (residual layers: after their 1x1 GEMM)
         // the previous layer's bottleneck GEMM (deferred by its layer_tail): the LDS image is still that layer's output
         if (a.has_hw && l > a.l_begin && wave < NWAVE / 2) {
             gv4f_ptr w_bp = (gv4f_ptr)(wblk - LAYER_STRIDE + WBOT_OFF) + lane;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             STAMP(sb + 4);
             gemm1x1_wino(out, xq + kk * 4, w_r1, pre_r1);
             STAMP(sb + 5);
+            if (l + 1 < a.l_end) pre_next = first_frags(l + 1);
             if (bot_here) {
 #pragma unroll
                 for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
                     if (p < wlim) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = out[m][o];
                 }
         }
-        layer_tail(l, lc);
+        layer_tail(l, lc, false);
         }
     };
 
