@@ -280,8 +280,11 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
 // ------------------------------------------------------------------------------------------------
 template <bool WINO>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
-    __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
+    // one allocation, so that the layout the Winograd tiles past the window rely on (constants right after the activation
+    // rows) is explicit
+    __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * LDS_S + MAX_LAYERS * CST_FLOATS];
+    float* const xs = lds;
+    float* const cst = lds + LDS_ROWS * LDS_S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
