@@ -74,7 +74,7 @@ def main():
     from dl4vc_amd.config import DanConfig
     from dl4vc_amd.model import DanNet
     from dl4vc_amd import synth
-    from oracle.dan_oracle import random_state_dict        # seeded weights of the reference's shapes
+    from dl4vc_amd.synth import random_state_dict          # seeded weights of the reference's shapes
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

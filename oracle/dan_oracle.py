@@ -232,62 +232,6 @@ def dan_forward_oracle(state_dict, cfg, reads, qual, strand, ref, ref_mask, var_
 # ----------------------------------------------------------------------------------------------
 # Seeded weights of the reference's shapes (used by tests, smoke and bench; no checkpoint offline)
 # ----------------------------------------------------------------------------------------------
-def sinusoid_pe(length: int, dim: int) -> np.ndarray:
-    """The registered buffer ``pe`` -- model.py:154-162."""
-    pos = np.arange(0.0, length, dtype=np.float32)[:, None]
-    div = np.exp(np.arange(0.0, dim, 2, dtype=np.float32) * np.float32(-(np.log(10000.0) / dim))).astype(np.float32)
-    pe = np.zeros((length, dim), dtype=np.float32)
-    pe[:, 0::2] = np.sin(pos * div)
-    pe[:, 1::2] = np.cos(pos * div)
-    return pe[None]
-
-
-def random_state_dict(cfg, seed: int = 0, dropout_keys: bool = True) -> Dict[str, np.ndarray]:
-    """Seeded N(0, 1/fan_in) weights with randomised BN statistics, reference key names and shapes
-    (SURVEY.md section 8b 'Weights contract').  Biases are N(0, 0.1)."""
-    spec = spec_from(cfg)
-    rng = np.random.default_rng(seed)
-    sd: Dict[str, np.ndarray] = {}
-
-    def w(*shape, fan_in=None):
-        fan_in = fan_in or int(np.prod(shape[1:]))
-        return (rng.standard_normal(shape) * np.sqrt(1.0 / fan_in)).astype(np.float32)
-
-    def bias(n):
-        return (rng.standard_normal(n) * 0.1).astype(np.float32)
-
-    sd["embeddings.weight"] = (rng.standard_normal((VOCAB, spec.embed_dim)) * 0.5).astype(np.float32)
-    sd["pe"] = sinusoid_pe(spec.length, spec.embed_dim)
-    for l in range(1, spec.layers + 1):
-        cin, cout, _ = spec.layer_dims(l)
-        # He-style gain (x2) keeps activations O(1) through the ReLU stack
-        sd["conv1D_layers.%d.weight" % (l - 1)] = w(cout, cin, 1, 3) * np.float32(np.sqrt(2.0))
-        sd["conv1D_layers.%d.bias" % (l - 1)] = bias(cout)
-        p = "bn1D_layers.%d." % (l - 1)
-        sd[p + "weight"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
-        sd[p + "bias"] = bias(cout)
-        sd[p + "running_mean"] = rng.uniform(0.0, 0.5, cout).astype(np.float32)
-        sd[p + "running_var"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
-        if spec.is_residual(l):
-            i = l - spec.residual_start
-            sd["residual_conv_layers.%d.weight" % i] = w(cout, cout, 1, 1)
-            sd["residual_conv_layers.%d.bias" % i] = bias(cout)
-        if spec.bottleneck > 0:
-            H = spec.bottleneck
-            sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)] = w(H, cout, 1, 1) * np.float32(np.sqrt(2.0))
-            sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)] = bias(H)
-            sd["conv1D_compression_layers.%d.weight" % (l - 1)] = w(H, H, 1, spec.length)
-            sd["conv1D_compression_layers.%d.bias" % (l - 1)] = bias(H)
-    sizes = [spec.feature_width] + list(spec.fc_sizes)
-    for i in range(len(sizes) - 1):
-        k = "conv2hidden.%d" % ((1 + 3 * i) if dropout_keys else 3 * i)
-        sd[k + ".weight"] = w(sizes[i + 1], sizes[i]) * np.float32(np.sqrt(2.0))
-        sd[k + ".bias"] = bias(sizes[i + 1])
-    hid = sizes[-1]
-    for name, n in (("fcHidden2BinTarget", 2), ("fcHidden2VT", 3), ("fcHidden2AF", 1),
-                    ("fcHidden2Coverage", 1), ("fcHidden2VB", VOCAB), ("fcHidden2VR", VOCAB)):
-        sd[name + ".weight"] = w(n, hid) * np.float32(2.0)
-        sd[name + ".bias"] = bias(n)
-    sd["bin_output_weights"] = np.full((1,), 0.1, np.float32)
-    sd["vt_output_weights"] = np.full((1,), 0.1, np.float32)
-    return sd
+# Seeded weights and the positional-encoding buffer are synthetic-data helpers of the package (dl4vc_amd/synth.py): the
+# benchmark needs them without touching the oracle.  Re-exported here for the tests and the golden generator.
+from dl4vc_amd.synth import sinusoid_pe, random_state_dict   # noqa: E402,F401

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from dl4vc_amd import synth, hdf5io, loader
 from dl4vc_amd.config import DanConfig
-from oracle.dan_oracle import random_state_dict
+from dl4vc_amd.synth import random_state_dict
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 td = tempfile.mkdtemp(prefix="e2e_")

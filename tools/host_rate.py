@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dl4vc_amd.config import DanConfig
 from dl4vc_amd.model import DanNet
 from dl4vc_amd import synth
-from oracle.dan_oracle import random_state_dict
+from dl4vc_amd.synth import random_state_dict
 cfg = DanConfig(reads=64)
 net = DanNet(cfg).load_state_dict(random_state_dict(cfg, seed=0))
 b = synth.tile_sites(synth.make_sites(256, reads=64, seed=0), 8192)
