@@ -220,14 +220,17 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
 #pragma unroll
         for (int n = 0; n < NT16; ++n) { pre_conv[n][0] = w0[n * 64]; pre_conv[n][1] = w0[n * 64 + (SPLIT ? W16_CONV_FRAGS : 0)]; }
     }
-    for (int i = tid; i < G::PLANES * G::PLANE / 8; i += SEG_THREADS) ((v4f*)xs)[i] = splat4(0.f);
-    for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
-        const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
-        cst[i] = *(const float*)(block(a.l_begin + l) + W16_CST_OFF + (size_t)j * 4);
-    }
-    __syncthreads();
+    auto stage_constants = [&]() {
+        for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
+            const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
+            cst[i] = *(const float*)(block(a.l_begin + l) + W16_CST_OFF + (size_t)j * 4);
+        }
+    };
 
     if (a.l_begin == 0) {
+        for (int i = tid; i < G::PLANES * G::PLANE / 8; i += SEG_THREADS) ((v4f*)xs)[i] = splat4(0.f);
+        stage_constants();
+        __syncthreads();
         // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, rounded to bf16 (hi [+ lo])
         const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
         int ok_ref = 1, ok_var = 1;
@@ -269,6 +272,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
             const int i = tid + k * SEG_THREADS;
             vy[k] = (i < n4) ? src[i] : splat4(0.f);
         }
+        // while the read is in flight: zero the rows it does not cover (halo rows and rows >= L, both planes) and stage
+        // the constants
+        constexpr int RV = S16 / 8;                               // 16-byte vectors per row
+        for (int i = tid; i < G::PLANES * (G::ROWS - L) * RV; i += SEG_THREADS) {
+            const int pl_i = i / ((G::ROWS - L) * RV), j = i - pl_i * ((G::ROWS - L) * RV);
+            const int rr = j / RV, c8 = j - rr * RV;
+            const int row = rr < HALO ? rr : rr + L;
+            *(v4f*)(xs + pl_i * G::PLANE + row * S16 + c8 * 8) = splat4(0.f);
+        }
+        stage_constants();
         if (pl) {
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
