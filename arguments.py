@@ -68,6 +68,8 @@ _EXTRA = [
     ("--shard", "str", "", "i/n: process only the i-th of n contiguous site shards (multi-GPU launch sets this)"),
     ("--precision", "str", "fp32", "conv-stack arithmetic: fp32 (exact fp32 MFMA, default), bf16x3 (split bf16, scores "
                                    "within 1e-4, ~2.3x faster) or bf16"),
+    ("--compute-empty-rows", "flag", False, "compute every all-padding pileup row separately, as the reference does (default: once "
+                                            "per site -- their inputs are identical, the outputs bit-identical)"),
     ("--conv-algo", "str", "auto", "fp32 conv form: auto (Winograd F(2,3) where every layer after the first has "
                                    "dilation 2), direct, or winograd"),
 ]
@@ -88,5 +90,8 @@ def create_arg_parser() -> argparse.ArgumentParser:
         else:
             p.add_argument(name, type=_TYPES[kind], default=default)
     for name, kind, default, text in _EXTRA:
-        p.add_argument(name, type=_TYPES[kind], default=default, help=text)
+        if kind == "flag":
+            p.add_argument(name, action="store_true", default=default, help=text)
+        else:
+            p.add_argument(name, type=_TYPES[kind], default=default, help=text)
     return p

@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--window", type=int, default=201)
     ap.add_argument("--conv-algo", type=int, default=0, help="fp32 conv form: 0 auto (Winograd F(2,3) on the dilation-2 "
                                                               "layers), 1 direct, 2 winograd")
+    ap.add_argument("--skip-empty-rows", action="store_true",
+                    help="compute the all-padding rows of each pileup once per site (bit-identical outputs; off for the headline, "
+                         "which computes every row like the reference)")
     args = ap.parse_args()
 
     import torch
@@ -98,7 +101,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision, conv_algo=args.conv_algo)
+    cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision, conv_algo=args.conv_algo,
+                    skip_empty_rows=args.skip_empty_rows)
     sd = random_state_dict(cfg, seed=0)
     net = DanNet(cfg, device_id=local_rank, chunk_sites=args.chunk_sites).load_state_dict(sd)
 
@@ -173,7 +177,9 @@ def main():
                                    "(7x conv128 dil2, residual 5-7, read-mean after L2, highway 32, FC %d->1024->256), "
                                    "seeded random weights" % (B, cfg.reads, cfg.length, cfg.feature_width),
                        "sites_per_gpu": B, "reads": cfg.reads, "window": cfg.length, "parallelism": "site-shard x%d" % world,
-                       "gflop_per_site": round(cfg.flops_per_site() / 1e9, 3)},
+                       "gflop_per_site": round(cfg.flops_per_site() / 1e9, 3),
+                       "skip_empty_rows": bool(cfg.skip_empty_rows),
+                       "empty_row_fraction": round(float((base.reads.reshape(-1, cfg.length).max(axis=1) == 0).mean()), 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,

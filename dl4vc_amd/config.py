@@ -47,6 +47,7 @@ class DanConfig:
     embed_dim: int = 20                      # embed_dim   (constructor default)
     precision: int = PRECISION_F32
     conv_algo: int = 0                       # fp32 path: 0 auto, 1 direct 3-tap GEMM, 2 Winograd F(2,3) (include/dl4vc_dan.h)
+    skip_empty_rows: bool = False            # all-padding pileup rows computed once per site (bit-identical outputs)
 
     def __post_init__(self):
         object.__setattr__(self, "pool_layers", tuple(int(p) for p in self.pool_layers))

@@ -55,6 +55,9 @@ struct dan_handle {
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
+    int* d_rowsrc = nullptr;                 // empty-row map of the current chunk (skip_empty_rows)
+    int *d_work = nullptr, *d_work_count = nullptr;   // ... and the list of rows to compute
+    int n_cus = 0;
     float *d_wc = nullptr, *d_bc = nullptr;
     float *d_feat = nullptr, *d_hid0 = nullptr, *d_hid1 = nullptr;
     float *d_w0 = nullptr, *d_b0 = nullptr, *d_w1 = nullptr, *d_b1 = nullptr, *d_wh = nullptr, *d_bh = nullptr;
@@ -241,6 +244,7 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     // Winograd F(2,3) form (dan_kernels.hip): fp32 path, and every conv after the first must have dilation 2
     const bool wino_ok = c.precision == 0 && (c.layers < 3 || c.dil_mid == 2) && (c.layers < 2 || c.dil_final == 2);
     if (c.conv_algo < 0 || c.conv_algo > 2) return fail(nullptr, DAN_ERR_INVALID_ARG, "conv_algo %d unknown (0 = auto, 1 = direct, 2 = winograd)", c.conv_algo);
+    if (c.skip_empty_rows < 0 || c.skip_empty_rows > 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "skip_empty_rows must be 0 or 1");
     if (c.conv_algo == 2 && !wino_ok)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "conv_algo 2 (winograd) needs precision 0 and dilation 2 on every conv layer after the first");
     int ndev = 0;
@@ -248,6 +252,7 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         return fail(nullptr, DAN_ERR_NO_DEVICE, "no HIP device %d (found %d): the DAN forward has no CPU path", c.device_id, ndev);
     dan_handle* h = new dan_handle();
     h->cfg = c;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device_id) == hipSuccess) h->n_cus = cus; }
     h->chunk = c.chunk_sites > 0 ? c.chunk_sites : 128;
     h->wino = wino_ok && c.conv_algo != 1;
     h->max_batch = c.max_batch > 0 ? c.max_batch : 4096;
@@ -426,6 +431,14 @@ int dan_finalize(dan_t* h) {
     const size_t read_floats = (size_t)L * CPAD;
     if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats))) return rc;
     if ((rc = dev_alloc(h, &h->d_pool, (size_t)h->chunk * read_floats))) return rc;
+    if (c.skip_empty_rows) {
+        float* tmp = nullptr;
+        if ((rc = dev_alloc(h, &tmp, (size_t)h->chunk * R))) return rc;     // int32 per pileup row
+        h->d_rowsrc = (int*)tmp;
+        if ((rc = dev_alloc(h, &tmp, (size_t)h->chunk * R + 4))) return rc;
+        h->d_work = (int*)tmp;
+        h->d_work_count = h->d_work + (size_t)h->chunk * R;
+    }
     if (H > 0 && (rc = dev_alloc(h, &h->d_h, (size_t)c.layers * h->chunk * R * L * HPAD))) return rc;
     if ((rc = dev_alloc(h, &h->d_feat, (size_t)h->max_batch * h->F_stride))) return rc;
     HIPCHK(h, hipMemset(h->d_feat, 0, (size_t)h->max_batch * h->F_stride * sizeof(float)));
@@ -469,6 +482,12 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
         for (int c0 = 0; c0 < nb; c0 += h->chunk) {
             const int ns = std::min(h->chunk, nb - c0);
             const int64_t g0 = mb + c0;                      // first site of the chunk in the caller's arrays
+            if (h->d_rowsrc) {
+                EventPair evm{};
+                int rcm = prof_begin(h, "row_map", s, &evm); if (rcm) return rcm;
+                launch_row_map(reads + g0 * rl, qual + g0 * rl, strand + g0 * rl, h->d_rowsrc, h->d_work, h->d_work_count, ns, R, L, s);
+                rcm = prof_end(h, "row_map", s, &evm); if (rcm) return rcm;
+            }
             for (int sg = 0; sg < h->n_segments; ++sg) {
                 SegmentArgs a{};
                 a.wl = h->d_wl;
@@ -487,35 +506,36 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 a.tap = tap_here ? h->d_tap : nullptr;
                 a.tap_layer = h->tap_layer;
                 a.wino = h->wino;
+                a.work = h->d_work; a.work_count = h->d_rowsrc ? h->d_work_count : nullptr;
                 EventPair ev{};
                 int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (c.precision == 0) {
-                    launch_segment(a, ns, s);
+                    launch_segment(a, ns, h->n_cus, s);
                 } else {
                     Segment16Args b{};
                     b.wl = h->d_wl16; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
                     b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
                     b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe; b.y = a.y; b.pool = a.pool;
-                    b.h = a.h; b.h_layer_stride = a.h_layer_stride; b.tap = a.tap; b.tap_layer = a.tap_layer;
+                    b.h = a.h; b.h_layer_stride = a.h_layer_stride; b.tap = a.tap; b.tap_layer = a.tap_layer; b.row_src = h->d_rowsrc;
                     launch_segment16(b, ns, c.precision, s);
                 }
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-                    launch_read_mean(h->d_y, h->d_pool, ns, R, L, s);
+                    launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
                     rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
                 }
             }
             float* feat = h->d_feat + (size_t)c0 * h->F_stride;
             EventPair ev{};
             int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-            launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, s);
+            launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
             if (H > 0) {
                 rc = prof_begin(h, "highway", s, &ev); if (rc) return rc;
                 launch_highway(h->d_h, h_layer_stride, h->d_wc, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat, h->F_stride,
-                               2 * c.c_final * L, ns, R, L, H, c.layers, s);
+                               2 * c.c_final * L, ns, R, L, H, c.layers, h->d_rowsrc, s);
                 rc = prof_end(h, "highway", s, &ev); if (rc) return rc;
             }
             h->last_chunk_sites = ns;

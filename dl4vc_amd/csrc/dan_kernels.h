@@ -67,9 +67,13 @@ struct SegmentArgs {
     float* tap;                  // [site][read][L][CPAD] or nullptr
     int tap_layer;               // 0 = encoded input, l = after conv layer l (1-based), -1 = none
     int wino;                    // 1: dilation-2 layers after the first run in Winograd F(2,3) form
+    int n_rows;                  // filled by launch_segment: n_sites * R
+    const int* work;             // rows to compute (device list, see launch_row_map); read only when work_count is set
+    const int* work_count;       // length of that list (device) or nullptr = every row
 };
 
-void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s);
+// max_wgs: workgroups to launch (one per CU: they are persistent and walk the rows with the grid's stride); 0 = one per row
+void launch_segment(const SegmentArgs& a, int n_sites, int max_wgs, hipStream_t s);
 
 // ---- bf16-MFMA family (dan_kernels_bf16.hip): precision 1 = bf16x3 (hi+lo split, L <= 208), 2 = bf16 (L <= 304)
 constexpr int S16 = 144;                 // bf16 elements per LDS position row (256 B + 32 B: conflict-free b128 reads)
@@ -101,17 +105,25 @@ struct Segment16Args {
     long long h_layer_stride;
     float* tap;
     int tap_layer;
+    const int* row_src;
 };
 void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s);
+// Empty-row map: a pileup row whose reads / qual / strand bytes are all zero (padding below the site's coverage) encodes to
+// the same activations as every other such row of its site, through every layer.  row_src[site*R + r] = site*R + (first
+// empty row of the site) for an empty row, site*R + r otherwise; the fp32 segment kernel walks only the rows that are their
+// own source (the bf16 ones exit early on the others) and the reductions read a skipped row's y / h through the map (bit-identical results).
+// work[0 .. *count) = the rows that are their own source, in row order.
+void launch_row_map(const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, int* row_src, int* work, int* count,
+                    int n_sites, int R, int L, hipStream_t s);
 // pool[site][p][c] = mean over reads of y[site][r][p][c]          (dl4vc/model.py:772)
-void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, hipStream_t s);
+void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s);
 // feat[site][c*L+p] = max_r y, feat[site][C*L + c*L+p] = mean_r y   (dl4vc/model.py:824-839)
 void launch_final_pool(const float* y, float* feat, long long feat_stride, int n_sites, int R, int L, int C,
-                       hipStream_t s);
+                       const int* row_src, hipStream_t s);
 // feat[site][off + l*H*R + o*R + r] = relu(sum_{p,c} Wc[l][o][c][p] h[l][site][r][p][c] + bc[l][o])   (model.py:776-777,859)
 void launch_highway(const float* h, long long h_layer_stride, const float* wc_packed, long long wc_layer_stride,
                     const float* bc, float* feat, long long feat_stride, int feat_off, int n_sites, int R, int L,
-                    int H, int layers, hipStream_t s);
+                    int H, int layers, const int* row_src, hipStream_t s);
 // C[M][N] = relu?(A[M][lda] * W[N][ldw]^T + bias)  over K (multiple of 16)
 void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
                long long ldc, int M, int N, int K, int relu, hipStream_t s);

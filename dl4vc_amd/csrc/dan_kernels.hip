@@ -37,7 +37,7 @@ constexpr int NSTAMP = 64;
         __builtin_amdgcn_sched_barrier(0);                                                            \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
-        if (lane == 0 && (k) < NSTAMP) g_stamps[((size_t)blockIdx.x * NWAVE + wave) * NSTAMP + (k)] = t_; \
+        if (lane == 0 && (k) < NSTAMP) g_stamps[((size_t)stamp_row * NWAVE + wave) * NSTAMP + (k)] = t_; \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #else
@@ -143,10 +143,10 @@ __device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
     const v2f hi = __builtin_elementwise_fma((v2f){b[2], b[3]}, m1, (v2f){a[2], a[3]});
     return (v4f){lo[0], lo[1], hi[0], hi[1]};
 }
-__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
+__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl) {
     v4f a_nxt[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a_nxt[k] = a_first[k];
+    for (int k = 0; k < 4; ++k) a_nxt[k] = wl[(size_t)(k * KGC) * (KGC * 64)];
     v4f xa = *(const v4f*)(xrow), xb = *(const v4f*)(xrow + 2 * LDS_S), xc = *(const v4f*)(xrow + 4 * LDS_S),
         xd = *(const v4f*)(xrow + 6 * LDS_S);
     float neg1 = -1.f;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
             v4f v = acc[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
-            *(v4f*)(hrow + (size_t)p * HPAD + n * 16 + kk * 4) = v;
+            *(v4f*)((char*)hrow + (unsigned)(p * HPAD + n * 16 + kk * 4) * 4u) = v;
         }
     }
 }
@@ -279,18 +279,32 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
 // segment kernel: one workgroup = one read, layers [l_begin, l_end) with the read resident in LDS
 // ------------------------------------------------------------------------------------------------
 template <bool WINO>
-__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a) {
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a_by_value) {
     // one allocation, so that the layout the Winograd tiles past the window rely on (constants right after the activation
     // rows) is explicit
     __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * LDS_S + MAX_LAYERS * CST_FLOATS];
     float* const xs = lds;
     float* const cst = lds + LDS_ROWS * LDS_S;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int site = blockIdx.x / a.R;
-    const int r = blockIdx.x - site * a.R;
+    typedef const __attribute__((address_space(4))) SegmentArgs* kernarg_ptr;
+    // Persistent workgroups: one per CU (the 152 KB of LDS allow no more), each walking the list of pileup rows with the
+    // grid's stride.  Dispatching 8192 workgroups per launch costs the command processor ~0.26 us each, serialised -- half
+    // the kernel's own duration -- and with empty-row skipping the rows to do are a device-side list anyway (a.work).
+    const int n_work = a_by_value.work_count ? *a_by_value.work_count : a_by_value.n_rows;
+    for (int wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+    // the arguments are re-read from the kernarg segment for every row (through a pointer the compiler cannot see
+    // through): kept in SGPRs across the row loop they, and what is derived from them, no longer fit
+    kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const auto& a = *ap;
     const int L = a.L;
+    [[maybe_unused]] const int stamp_row = wk;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                           // per-row: nothing derived from the thread index is hoisted out of
+    const int lane = tid & 63;                              // the row loop (it would live through every GEMM and spill)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_index = a.work_count ? a.work[wk] : wk;
+    const int site = row_index / a.R;
+    const int r = row_index - site * a.R;
     const size_t read_idx = (size_t)site * a.R + r;
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
     const int pos = lane & 15, kk = lane >> 4;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     };
     // (a resumed segment of the WINO instantiation asks for them after its 52-load prologue instead: no registers to spare)
     Frags pre_conv = {}, pre_next = {};
-    if (!WINO || a.l_begin == 0) pre_conv = first_frags(a.l_begin);
+    if (!WINO || a.l_begin == 0) pre_conv = first_frags(a.l_begin);     // (the Winograd GEMM fetches its own first fragments)
     auto stage_constants = [&]() {
         for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
             const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
@@ -404,7 +418,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             const int i = tid + k * SEG_THREADS;
             if (i < n4) *(v4f*)(xs + (HALO + (i >> 5)) * LDS_S + (i & 31) * 4) = vy[k] + vp[k];
         }
-        if (WINO) pre_conv = first_frags(a.l_begin);
     }
     __syncthreads();
     STAMP(1);
@@ -421,9 +434,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             asm volatile("" : "+v"(t));
             copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, t);
         }
-        // WINO instantiation, direct first layer: the next conv's first four weight fragments are requested here (its
-        // Winograd layers request them after their output transform / residual GEMM)
-        if (WINO && late_prefetch && l + 1 < a.l_end) pre_next = first_frags(l + 1);
         // WINO instantiation, not the segment's last layer: the bottleneck GEMM of this layer is deferred into the next
         // layer's conv stage, where the four older waves run it on the same LDS-resident input while the younger wave of
         // each SIMD is still in its conv GEMM (the arbiter serves the older wave first, so it finishes the conv early and
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             bottleneck<NWAVE>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L,
                               wave, lane);
         STAMP(sb + 7);
-        pre_conv = pre_next;
+        if (!WINO) pre_conv = pre_next;
     };
 
     // ---- direct form: wave = (channel quarter, position half), 3-tap implicit GEMM
@@ -584,8 +594,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 #pragma unroll
             for (int m = 0; m < MW; ++m) { acc[m][0] = splat(0.f); acc[m][1] = bias; acc[m][2] = splat(0.f); acc[m][3] = splat(0.f); }
             STAMP(sb + 0);
-            const v4f pre_w[4] = {pre_conv.f0, pre_conv.f1, pre_conv.f2, pre_conv.f3};
-            conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w, pre_w);
+            conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w);
             STAMP(sb + 1);
             asm volatile("" : "+v"(wp));       // keeps everything derived from it (addresses, masks) out of the GEMM's live set
             xq = xs + (HALO + wp) * LDS_S;
@@ -606,7 +615,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         // fragments are requested only now (the barriers, the write-back and the residual GEMM cover their latency)
         __builtin_amdgcn_sched_barrier(0);
         pre_r1 = residual ? w_r1[0] : splat(0.f);
-        if (!residual && l + 1 < a.l_end) pre_next = first_frags(l + 1);      // (residual layers: after their 1x1 GEMM)
         // the previous layer's bottleneck GEMM (deferred by its layer_tail): the LDS image is still that layer's output
         if (a.has_hw && l > a.l_begin && wave < NWAVE / 2) {
             gv4f_ptr w_bp = (gv4f_ptr)(wblk - LAYER_STRIDE + WBOT_OFF) + lane;
@@ -632,7 +640,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
                     const int p = wp + 4 * m + 2 * o;
                     if (p < wlim) {
                         v4f* cell = (v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw);
-                        const v4f old = from_global ? ((p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chw) : splat(0.f)) : *cell;
+                        // (uniform base + 32-bit lane offset: one VGPR per address instead of a 64-bit pair)
+                        const v4f old = from_global ? ((p < L) ? *(const v4f*)((const char*)yrow + (unsigned)(p * CPAD + chw) * 4u) : splat(0.f)) : *cell;
                         *cell = out[m][o];
                         out[m][o] = old + bres;
                     }
@@ -641,7 +650,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             STAMP(sb + 4);
             gemm1x1_wino(out, xq + kk * 4, w_r1, pre_r1);
             STAMP(sb + 5);
-            if (l + 1 < a.l_end) pre_next = first_frags(l + 1);
             if (bot_here) {
 #pragma unroll
                 for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
@@ -678,35 +686,105 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     STAMP(62);
     copy_out(xs, yrow, L, tid);
     STAMP(63);
+    __syncthreads();                                        // the next row re-uses the LDS image
+    }   // rows of this workgroup
 }
 
-void launch_segment(const SegmentArgs& a, int n_sites, hipStream_t s) {
-    if (a.wino) hipLaunchKernelGGL(segment_kernel<true>, dim3((unsigned)(n_sites * a.R)), dim3(SEG_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(segment_kernel<false>, dim3((unsigned)(n_sites * a.R)), dim3(SEG_THREADS), 0, s, a);
+void launch_segment(const SegmentArgs& a0, int n_sites, int max_wgs, hipStream_t s) {
+    SegmentArgs a = a0;
+    a.n_rows = n_sites * a.R;
+    const unsigned grid = (unsigned)((max_wgs > 0 && max_wgs < a.n_rows) ? max_wgs : a.n_rows);
+    if (a.wino) hipLaunchKernelGGL(segment_kernel<true>, dim3(grid), dim3(SEG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(segment_kernel<false>, dim3(grid), dim3(SEG_THREADS), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
 // site-level reductions over the read axis (sequential r = 0..R-1 fp32 sums, like AvgPool2d on CPU)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void read_mean_kernel(const v4f* __restrict__ y, v4f* __restrict__ pool, int R, int L) {
+// the empty-row map of one site (see dan_kernels.h): one workgroup per site, one wave per row in turn
+__global__ __launch_bounds__(256) void row_map_kernel(const uint8_t* __restrict__ reads, const uint8_t* __restrict__ qual,
+                                                      const uint8_t* __restrict__ strand, int* __restrict__ row_src, int R, int L) {
+    __shared__ int empty[1024];
+    const int site = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < R; r += 4) {
+        const size_t base = ((size_t)site * R + r) * L;
+        unsigned any = 0;
+        for (int p = lane; p < L; p += 64) any |= (unsigned)reads[base + p] | (unsigned)qual[base + p] | (unsigned)strand[base + p];
+        const bool none = __ballot(any != 0) == 0ull;
+        if (lane == 0 && r < 1024) empty[r] = none;
+    }
+    __syncthreads();
+    int first = -1;
+    for (int r = 0; r < R && r < 1024; ++r)
+        if (empty[r]) { first = r; break; }
+    for (int r = tid; r < R; r += 256) row_src[(size_t)site * R + r] = site * R + ((r < 1024 && empty[r]) ? first : r);
+}
+
+// rows that are their own source, in row order: work[0 .. *count)
+__global__ __launch_bounds__(1024) void work_list_kernel(const int* __restrict__ row_src, int* __restrict__ work,
+                                                         int* __restrict__ count, int n_sites, int R) {
+    __shared__ int offs[4096 + 1];
+    const int tid = threadIdx.x;
+    int total = 0;
+    for (int base = 0; base < n_sites; base += 4096) {                      // (one pass unless a chunk exceeds 4096 sites)
+        const int n = min(4096, n_sites - base);
+        for (int sidx = tid; sidx < n; sidx += 1024) {
+            int c = 0;
+            const int* rs = row_src + (size_t)(base + sidx) * R;
+            for (int r = 0; r < R; ++r) c += rs[r] == (base + sidx) * R + r;
+            offs[sidx + 1] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            offs[0] = total;
+            for (int i = 0; i < n; ++i) offs[i + 1] += offs[i];
+        }
+        __syncthreads();
+        for (int sidx = tid; sidx < n; sidx += 1024) {
+            int o = offs[sidx];
+            const int* rs = row_src + (size_t)(base + sidx) * R;
+            for (int r = 0; r < R; ++r)
+                if (rs[r] == (base + sidx) * R + r) work[o++] = (base + sidx) * R + r;
+        }
+        total = offs[n];
+        __syncthreads();
+    }
+    if (tid == 0) *count = total;
+}
+
+void launch_row_map(const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, int* row_src, int* work, int* count,
+                    int n_sites, int R, int L, hipStream_t s) {
+    hipLaunchKernelGGL(row_map_kernel, dim3(n_sites), dim3(256), 0, s, reads, qual, strand, row_src, R, L);
+    hipLaunchKernelGGL(work_list_kernel, dim3(1), dim3(1024), 0, s, row_src, work, count, n_sites, R);
+}
+
+__global__ __launch_bounds__(256) void read_mean_kernel(const v4f* __restrict__ y, v4f* __restrict__ pool, int R, int L,
+                                                        const int* __restrict__ row_src) {
     const int n4 = L * (CPAD / 4);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int site = blockIdx.y;
-    const v4f* src = y + (size_t)site * R * n4 + i;
     v4f sum = splat(0.f);
+    if (row_src) {                                          // same rows, same order: skipped rows are read through the map
+        const int* rs = row_src + (size_t)site * R;
 #pragma unroll 8
-    for (int r = 0; r < R; ++r) sum += src[(size_t)r * n4];
+        for (int r = 0; r < R; ++r) sum += y[(size_t)rs[r] * n4 + i];
+    } else {
+        const v4f* src = y + (size_t)site * R * n4 + i;
+#pragma unroll 8
+        for (int r = 0; r < R; ++r) sum += src[(size_t)r * n4];
+    }
     pool[(size_t)site * n4 + i] = sum / splat((float)R);
 }
 
-void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, hipStream_t s) {
+void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s) {
     const int n4 = L * (CPAD / 4);
-    hipLaunchKernelGGL(read_mean_kernel, dim3((n4 + 255) / 256, n_sites), dim3(256), 0, s, (const v4f*)y, (v4f*)pool, R, L);
+    hipLaunchKernelGGL(read_mean_kernel, dim3((n4 + 255) / 256, n_sites), dim3(256), 0, s, (const v4f*)y, (v4f*)pool, R, L,
+                       row_src);
 }
 
 __global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__ y, float* __restrict__ feat,
-                                                         long long fs, int R, int L, int C) {
+                                                         long long fs, int R, int L, int C, const int* __restrict__ row_src) {
     __shared__ float tmax[CPAD * 17], tavg[CPAD * 17];
     const int pt = blockIdx.x, site = blockIdx.y, tid = threadIdx.x;
     const int c4 = tid & 31, pl = tid >> 5;
@@ -716,12 +794,14 @@ __global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__
         const int pp = half * 8 + pl, p = pt * 16 + pp;
         v4f mx = splat(0.f), av = splat(0.f);
         if (p < L) {
-            const v4f* src = y + (size_t)site * R * n4 + (size_t)p * (CPAD / 4) + c4;
-            mx = src[0];
-            v4f sum = src[0];
+            const size_t off = (size_t)p * (CPAD / 4) + c4;
+            const int* rs = row_src ? row_src + (size_t)site * R : nullptr;
+            auto row = [&](int r) { return rs ? y[(size_t)rs[r] * n4 + off] : y[((size_t)site * R + r) * n4 + off]; };
+            mx = row(0);
+            v4f sum = mx;
 #pragma unroll 8
             for (int r = 1; r < R; ++r) {
-                const v4f v = src[(size_t)r * n4];
+                const v4f v = row(r);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], v[j]);
                 sum += v;
@@ -745,8 +825,10 @@ __global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__
     }
 }
 
-void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, int R, int L, int C, hipStream_t s) {
-    hipLaunchKernelGGL(final_pool_kernel, dim3((L + 15) / 16, n_sites), dim3(256), 0, s, (const v4f*)y, feat, fs, R, L, C);
+void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, int R, int L, int C, const int* row_src,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(final_pool_kernel, dim3((L + 15) / 16, n_sites), dim3(256), 0, s, (const v4f*)y, feat, fs, R, L, C,
+                       row_src);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -760,7 +842,8 @@ constexpr int HW_RT = 2;                                    // 16-read row tiles
 __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ h, long long hls,
                                                       const v4f* __restrict__ wc, long long wcls,
                                                       const float* __restrict__ bc, float* __restrict__ feat,
-                                                      long long fs, int feat_off, int n_rows, int R, int L, int H) {
+                                                      long long fs, int feat_off, int n_rows, int R, int L, int H,
+                                                      const int* __restrict__ row_src) {
     __shared__ float part[HW_WAVES][HW_RT][2][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
@@ -771,7 +854,10 @@ __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ 
     const int g_lo = (int)((long long)G * wave / HW_WAVES), g_hi = (int)((long long)G * (wave + 1) / HW_WAVES);
     const float* arow[HW_RT];
 #pragma unroll
-    for (int i = 0; i < HW_RT; ++i) arow[i] = h + (size_t)layer * hls + (size_t)min(row0 + 16 * i + r16, n_rows - 1) * K + kk * 4;
+    for (int i = 0; i < HW_RT; ++i) {
+        const int row = min(row0 + 16 * i + r16, n_rows - 1);
+        arow[i] = h + (size_t)layer * hls + (size_t)(row_src ? row_src[row] : row) * K + kk * 4;   // skipped rows: their source's h
+    }
     const v4f* wl = wc + (size_t)layer * wcls + lane;
     v4f acc[HW_RT][2];
 #pragma unroll
@@ -833,10 +919,11 @@ __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ 
 }
 
 void launch_highway(const float* h, long long hls, const float* wc, long long wcls, const float* bc, float* feat,
-                    long long fs, int feat_off, int n_sites, int R, int L, int H, int layers, hipStream_t s) {
+                    long long fs, int feat_off, int n_sites, int R, int L, int H, int layers, const int* row_src,
+                    hipStream_t s) {
     const int n_rows = n_sites * R;
     hipLaunchKernelGGL(highway_kernel, dim3((n_rows + 16 * HW_RT - 1) / (16 * HW_RT), layers), dim3(512), 0, s, h, hls, (const v4f*)wc,
-                       wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H);
+                       wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H, row_src);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
     const int site = blockIdx.x / a.R, r = blockIdx.x - site * a.R;
     const int L = a.L;
     const size_t read_idx = (size_t)site * a.R + r;
+    if (a.row_src && a.row_src[read_idx] != (int)read_idx) return;      // an empty duplicate (see launch_row_map)
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
     const int pos = lane & 15, kq = lane >> 4;
     int chb[NT16];

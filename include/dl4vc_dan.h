@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DAN_ABI_VERSION 2
+#define DAN_ABI_VERSION 3
 #define DAN_MAX_LAYERS 16
 
 typedef enum dan_status {
@@ -60,6 +60,10 @@ typedef struct dan_config {
                                * GEMM; 2 = Winograd F(2,3) over the dilated positions (needs every such layer to
                                * have dilation 2: 4 exact-fp32 GEMMs per 2 outputs instead of 6); 0 = Winograd
                                * where it applies, else direct                                     */
+    int32_t skip_empty_rows;  /* 1 = compute the all-padding rows of a pileup (reads, q-scores and strand bytes all zero:
+                               * the rows below the site's coverage) once per site and let every other such row use
+                               * that result -- their encoded input is identical, so every output is bit-identical to
+                               * computing all rows (which is what 0 does, and what the reference does)              */
 } dan_config;
 
 typedef struct dan_handle dan_t;

@@ -42,7 +42,8 @@ def main(argv=None) -> int:
         raise SystemExit("--conv-algo must be auto, direct or winograd")
     import dataclasses
     cfg = dataclasses.replace(cfg, precision=("fp32", "bf16x3", "bf16").index(args.precision),
-                              conv_algo=("auto", "direct", "winograd").index(args.conv_algo))
+                              conv_algo=("auto", "direct", "winograd").index(args.conv_algo),
+                              skip_empty_rows=not args.compute_empty_rows)
     shard_i, shard_n = parse_shard(args.shard)
     if args.save_vcf_records:
         assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"

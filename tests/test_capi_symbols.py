@@ -51,8 +51,8 @@ def test_abi_version(lib):
 
 
 def test_config_struct_layout():
-    # 21 x 4-byte fields, no padding: must match struct dan_config in the header
-    assert ctypes.sizeof(capi.DanCConfig) == 4 * 21
+    # 22 x 4-byte fields, no padding: must match struct dan_config in the header
+    assert ctypes.sizeof(capi.DanCConfig) == 4 * 22
     cc = capi.c_config(production_config(reads=64), device_id=3)
     assert (cc.reads, cc.length, cc.layers, cc.device_id) == (64, 201, 7, 3)
     assert cc.pool_layers_mask == 1 << 2 and list(cc.fc_sizes) == [1024, 256]

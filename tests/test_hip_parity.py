@@ -233,3 +233,27 @@ def test_winograd_needs_dilation_two():
         DanNet(DanConfig(reads=8, dil_mid=1, conv_algo=2))
     net = DanNet(DanConfig(reads=8, dil_mid=1, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8)))   # auto -> direct
     net.close()
+
+
+@pytest.mark.parametrize("precision,algo", [(0, 0), (0, 1), (1, 0)])
+def test_skipping_empty_rows_is_bit_identical(precision, algo):
+    """All-padding rows of a pileup encode identically, so computing them once per site changes no output bit; covers a
+    site without empty rows, a site of only empty rows and rows that are empty in reads but not in q-scores (not skipped)."""
+    kw = dict(reads=24, c_init=48, c_final=48, bottleneck=8, fc_sizes=(32, 16), precision=precision, conv_algo=algo)
+    sd = random_state_dict(DanConfig(**kw), seed=51)
+    batch = synth.make_sites(9, reads=24, seed=52)
+    arrs = [a.copy() for a in batch.arrays()]
+    reads, qual, strand = arrs[0], arrs[1], arrs[2]
+    empty = reads.max(axis=2) == 0
+    assert empty.any() and not empty.all()
+    reads[0], qual[0], strand[0] = 0, 0, 0                      # a site of only empty rows
+    reads[1, empty[1]] = 3; qual[1, empty[1]] = 7                # a site without empty rows
+    r = int(np.flatnonzero(empty[2])[0])
+    qual[2, r, 5] = 9                                             # reads empty, q-scores not: must be computed on its own
+    outs = []
+    for skip in (False, True):
+        net = DanNet(DanConfig(skip_empty_rows=skip, **kw)).load_state_dict(sd)
+        outs.append(net.forward_u8(*arrs, aux=True))
+        net.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
