@@ -517,8 +517,8 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                     b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
                     b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe; b.y = a.y; b.pool = a.pool;
-                    b.h = a.h; b.h_layer_stride = a.h_layer_stride; b.tap = a.tap; b.tap_layer = a.tap_layer; b.row_src = h->d_rowsrc;
-                    launch_segment16(b, ns, c.precision, s);
+                    b.h = a.h; b.h_layer_stride = a.h_layer_stride; b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
+                    launch_segment16(b, ns, c.precision, h->n_cus, s);
                 }
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {

@@ -105,13 +105,15 @@ struct Segment16Args {
     long long h_layer_stride;
     float* tap;
     int tap_layer;
-    const int* row_src;
+    int n_rows;                  // as in SegmentArgs
+    const int* work;
+    const int* work_count;
 };
-void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s);
+void launch_segment16(const Segment16Args& a, int n_sites, int precision, int max_wgs, hipStream_t s);
 // Empty-row map: a pileup row whose reads / qual / strand bytes are all zero (padding below the site's coverage) encodes to
 // the same activations as every other such row of its site, through every layer.  row_src[site*R + r] = site*R + (first
-// empty row of the site) for an empty row, site*R + r otherwise; the fp32 segment kernel walks only the rows that are their
-// own source (the bf16 ones exit early on the others) and the reductions read a skipped row's y / h through the map (bit-identical results).
+// empty row of the site) for an empty row, site*R + r otherwise; the segment kernels walk only the rows that are their own
+// source and the reductions read a skipped row's y / h through the map (bit-identical results).
 // work[0 .. *count) = the rows that are their own source, in row order.
 void launch_row_map(const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, int* row_src, int* work, int* count,
                     int n_sites, int R, int L, hipStream_t s);

@@ -143,10 +143,10 @@ __device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
     const v2f hi = __builtin_elementwise_fma((v2f){b[2], b[3]}, m1, (v2f){a[2], a[3]});
     return (v4f){lo[0], lo[1], hi[0], hi[1]};
 }
-__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl) {
+__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
     v4f a_nxt[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a_nxt[k] = wl[(size_t)(k * KGC) * (KGC * 64)];
+    for (int k = 0; k < 4; ++k) a_nxt[k] = a_first[k];
     v4f xa = *(const v4f*)(xrow), xb = *(const v4f*)(xrow + 2 * LDS_S), xc = *(const v4f*)(xrow + 4 * LDS_S),
         xd = *(const v4f*)(xrow + 6 * LDS_S);
     float neg1 = -1.f;
@@ -278,7 +278,12 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
 // ------------------------------------------------------------------------------------------------
 // segment kernel: one workgroup = one read, layers [l_begin, l_end) with the read resident in LDS
 // ------------------------------------------------------------------------------------------------
-template <bool WINO>
+// PERSIST = false: one workgroup per pileup row (the default: every row is computed).  PERSIST = true: one workgroup per
+// CU walking the device-side list of rows to do with the grid's stride -- used with empty-row skipping, where dispatching
+// a workgroup per row only to have a quarter of them exit costs the command processor ~0.26 us each, serialised.  The row
+// loop costs registers (what is live across rows), so that form re-reads its arguments per row and does without the
+// cross-layer weight prefetch; it is ~1 % slower per computed row.
+template <bool WINO, bool PERSIST>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a_by_value) {
     // one allocation, so that the layout the Winograd tiles past the window rely on (constants right after the activation
     // rows) is explicit
@@ -286,24 +291,28 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     float* const xs = lds;
     float* const cst = lds + LDS_ROWS * LDS_S;
     typedef const __attribute__((address_space(4))) SegmentArgs* kernarg_ptr;
-    // Persistent workgroups: one per CU (the 152 KB of LDS allow no more), each walking the list of pileup rows with the
-    // grid's stride.  Dispatching 8192 workgroups per launch costs the command processor ~0.26 us each, serialised -- half
-    // the kernel's own duration -- and with empty-row skipping the rows to do are a device-side list anyway (a.work).
+    // (the row body sits at function scope with an explicit back edge: wrapped in a lambda, or in a for loop left by a
+    // compile-time break, the same code costs the non-persistent form 56 spilled registers)
     const int n_work = a_by_value.work_count ? *a_by_value.work_count : a_by_value.n_rows;
-    for (int wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
-    // the arguments are re-read from the kernarg segment for every row (through a pointer the compiler cannot see
-    // through): kept in SGPRs across the row loop they, and what is derived from them, no longer fit
+    int wk = blockIdx.x;
+    if (wk >= n_work) return;
+next_row:                                                   // (PERSIST only: back edge at the bottom)
+    {
+    // PERSIST: the arguments are re-read from the kernarg segment for every row through a pointer the compiler cannot see
+    // through -- kept in SGPRs across the row loop they, and what is derived from them, no longer fit.  The one-row form
+    // reads the by-value parameter directly (through the pointer it spills 57 registers).
     kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ap));
-    const auto& a = *ap;
+    if (PERSIST) asm volatile("" : "+s"(ap));
+    auto args = [&]() -> decltype(auto) { if constexpr (PERSIST) return (*ap); else return (a_by_value); };
+    const auto& a = args();
     const int L = a.L;
     [[maybe_unused]] const int stamp_row = wk;
     int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));                           // per-row: nothing derived from the thread index is hoisted out of
+    if (PERSIST) asm volatile("" : "+v"(tid));              // per-row: nothing derived from the thread index is hoisted out of
     const int lane = tid & 63;                              // the row loop (it would live through every GEMM and spill)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row_index = a.work_count ? a.work[wk] : wk;
-    const int site = row_index / a.R;
+    const int row_index = __builtin_amdgcn_readfirstlane(a.work_count ? a.work[wk] : wk);     // uniform: everything derived stays scalar
+    const int site = (int)((unsigned)row_index / (unsigned)a.R);
     const int r = row_index - site * a.R;
     const size_t read_idx = (size_t)site * a.R + r;
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
@@ -321,25 +330,23 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     [[maybe_unused]] const int chw = wave * 16 + kk * 4;
     auto dil_of = [&](int l) { return (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final); };
     auto wino_layer = [&](int l) { return WINO && l > 0; };
-    // first conv's first weight fragments: in flight during the whole prologue
-    // (named members, returned by value: arrays captured by reference in the layer lambdas end up in scratch memory)
-    struct Frags { v4f f0, f1, f2, f3; };
-    auto first_frags = [&](int l) -> Frags {
+    // First weight fragments of a conv GEMM, requested a stage ahead of it (eight plain vector variables: an aggregate, or an
+    // array, captured by reference in the layer lambdas ends up in scratch memory).  The PERSIST Winograd form has no
+    // registers to carry them across stages: its conv GEMM fetches its own.
+    constexpr bool CARRY = !(WINO && PERSIST);
+    v4f pc0 = splat(0.f), pc1 = pc0, pc2 = pc0, pc3 = pc0, pn0 = pc0, pn1 = pc0, pn2 = pc0, pn3 = pc0;
+    auto first_frags = [&](int l, v4f& f0, v4f& f1, v4f& f2, v4f& f3) {
         const float* blk = a.wl + (size_t)l * LAYER_STRIDE;
-        Frags r;
         if (wino_layer(l)) {
             gv4f_ptr w0 = (gv4f_ptr)(blk + WW_OFF) + wave * 64 + lane;
             constexpr size_t KS = (size_t)KGC * (KGC * 64);
-            r.f0 = w0[0]; r.f1 = w0[KS]; r.f2 = w0[2 * KS]; r.f3 = w0[3 * KS];
+            f0 = w0[0]; f1 = w0[KS]; f2 = w0[2 * KS]; f3 = w0[3 * KS];
         } else {
             gv4f_ptr w0 = (gv4f_ptr)(blk + W_OFF) + (cq * NT) * 64 + lane;
-            r.f0 = w0[0]; r.f1 = w0[64]; r.f2 = r.f0; r.f3 = r.f1;
+            f0 = w0[0]; f1 = w0[64];
         }
-        return r;
     };
-    // (a resumed segment of the WINO instantiation asks for them after its 52-load prologue instead: no registers to spare)
-    Frags pre_conv = {}, pre_next = {};
-    if (!WINO || a.l_begin == 0) pre_conv = first_frags(a.l_begin);     // (the Winograd GEMM fetches its own first fragments)
+    if (!WINO || a.l_begin == 0) first_frags(a.l_begin, pc0, pc1, pc2, pc3);
     auto stage_constants = [&]() {
         for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
             const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             const int i = tid + k * SEG_THREADS;
             if (i < n4) *(v4f*)(xs + (HALO + (i >> 5)) * LDS_S + (i & 31) * 4) = vy[k] + vp[k];
         }
+        if (WINO && CARRY) first_frags(a.l_begin, pc0, pc1, pc2, pc3);   // (after the 52-load prologue: no registers to spare before)
     }
     __syncthreads();
     STAMP(1);
@@ -434,6 +442,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             asm volatile("" : "+v"(t));
             copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, t);
         }
+        if (WINO && CARRY && late_prefetch && l + 1 < a.l_end) first_frags(l + 1, pn0, pn1, pn2, pn3);   // (direct first layer of the Winograd form)
         // WINO instantiation, not the segment's last layer: the bottleneck GEMM of this layer is deferred into the next
         // layer's conv stage, where the four older waves run it on the same LDS-resident input while the younger wave of
         // each SIMD is still in its conv GEMM (the arbiter serves the older wave first, so it finishes the conv early and
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             bottleneck<NWAVE>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L,
                               wave, lane);
         STAMP(sb + 7);
-        if (!WINO) pre_conv = pre_next;
+        if (CARRY) { pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3; }
     };
 
     // ---- direct form: wave = (channel quarter, position half), 3-tap implicit GEMM
@@ -458,15 +467,15 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
         // first fragments of the later GEMM stages of this layer and of the next conv: loaded now, used after
         // the conv GEMM, so their L2 latency is never exposed
-        if (!WINO && l + 1 < a.l_end) pre_next = first_frags(l + 1);
+        if (!WINO && l + 1 < a.l_end) first_frags(l + 1, pn0, pn1, pn2, pn3);
         // x_in of a residual layer is the layer input BEFORE the pool add (model.py:732): for the first layer of a
         // pooled segment it is re-read from HBM
         const bool from_global = (l == a.l_begin) && (a.l_begin != 0) && (a.pool != nullptr);
         v4f pre_res[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) pre_res[n] = residual ? w_res[n * 64] : splat(0.f);
-        static_assert(NT == 2, "Frags holds two direct-form fragments");
-        const v4f pre_dir[NT] = {pre_conv.f0, pre_conv.f1};
+        static_assert(NT == 2, "two direct-form fragments are carried");
+        const v4f pre_dir[NT] = {pc0, pc1};
 
         v4f acc[MTW][NT];
         {
@@ -594,7 +603,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
 #pragma unroll
             for (int m = 0; m < MW; ++m) { acc[m][0] = splat(0.f); acc[m][1] = bias; acc[m][2] = splat(0.f); acc[m][3] = splat(0.f); }
             STAMP(sb + 0);
-            conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w);
+            if constexpr (CARRY) {
+                const v4f pre_w[4] = {pc0, pc1, pc2, pc3};
+                conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w, pre_w);
+            } else {
+                gv4f_ptr w0 = w_w;
+                const v4f pre_w[4] = {w0[0], w0[(size_t)KGC * (KGC * 64)], w0[(size_t)2 * KGC * (KGC * 64)], w0[(size_t)3 * KGC * (KGC * 64)]};
+                conv_gemm_wino(acc, xw - 2 * LDS_S + kk * 4, w_w, pre_w);
+            }
             STAMP(sb + 1);
             asm volatile("" : "+v"(wp));       // keeps everything derived from it (addresses, masks) out of the GEMM's live set
             xq = xs + (HALO + wp) * LDS_S;
@@ -615,6 +631,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
         // fragments are requested only now (the barriers, the write-back and the residual GEMM cover their latency)
         __builtin_amdgcn_sched_barrier(0);
         pre_r1 = residual ? w_r1[0] : splat(0.f);
+        if (CARRY && !residual && l + 1 < a.l_end) first_frags(l + 1, pn0, pn1, pn2, pn3);      // (residual layers: after their 1x1 GEMM)
         // the previous layer's bottleneck GEMM (deferred by its layer_tail): the LDS image is still that layer's output
         if (a.has_hw && l > a.l_begin && wave < NWAVE / 2) {
             gv4f_ptr w_bp = (gv4f_ptr)(wblk - LAYER_STRIDE + WBOT_OFF) + lane;
@@ -650,6 +667,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
             STAMP(sb + 4);
             gemm1x1_wino(out, xq + kk * 4, w_r1, pre_r1);
             STAMP(sb + 5);
+            if (CARRY && l + 1 < a.l_end) first_frags(l + 1, pn0, pn1, pn2, pn3);
             if (bot_here) {
 #pragma unroll
                 for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
@@ -686,16 +704,26 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     STAMP(62);
     copy_out(xs, yrow, L, tid);
     STAMP(63);
-    __syncthreads();                                        // the next row re-uses the LDS image
-    }   // rows of this workgroup
+    }
+    if constexpr (PERSIST) {
+        wk += gridDim.x;
+        __syncthreads();                                    // the next row re-uses the LDS image
+        if (wk < n_work) goto next_row;
+    }
 }
 
 void launch_segment(const SegmentArgs& a0, int n_sites, int max_wgs, hipStream_t s) {
     SegmentArgs a = a0;
     a.n_rows = n_sites * a.R;
-    const unsigned grid = (unsigned)((max_wgs > 0 && max_wgs < a.n_rows) ? max_wgs : a.n_rows);
-    if (a.wino) hipLaunchKernelGGL(segment_kernel<true>, dim3(grid), dim3(SEG_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(segment_kernel<false>, dim3(grid), dim3(SEG_THREADS), 0, s, a);
+    const bool persist = a.work_count != nullptr && max_wgs > 0 && max_wgs < a.n_rows;
+    const dim3 grid((unsigned)(persist ? max_wgs : a.n_rows)), blk(SEG_THREADS);
+    if (persist) {
+        if (a.wino) hipLaunchKernelGGL((segment_kernel<true, true>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((segment_kernel<false, true>), grid, blk, 0, s, a);
+    } else {
+        if (a.wino) hipLaunchKernelGGL((segment_kernel<true, false>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((segment_kernel<false, false>), grid, blk, 0, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

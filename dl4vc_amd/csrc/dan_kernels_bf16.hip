@@ -28,7 +28,7 @@ extern __device__ unsigned long long* g_stamps;
         __builtin_amdgcn_sched_barrier(0);                                                            \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
-        if (lane == 0 && (k) < 64) g_stamps[((size_t)blockIdx.x * NWAVE + wave) * 64 + (k)] = t_;     \
+        if (lane == 0 && (k) < 64) g_stamps[((size_t)stamp_row * NWAVE + wave) * 64 + (k)] = t_;     \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #else
@@ -195,17 +195,25 @@ __device__ __forceinline__ void copy_out16(const __bf16* xs, float* dst, int L, 
     }
 }
 
-template <bool SPLIT, int MT>
-__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segment16Args a) {
+// PERSIST: one workgroup per CU walking the row list (used with empty-row skipping, where the rows to do are a device-side
+// list); otherwise one workgroup per row -- the row loop costs these kernels registers they do not have (spills, -10 %).
+template <bool SPLIT, int MT, bool PERSIST>
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segment16Args a_by_value) {
     typedef Geo<SPLIT, MT> G;
     __shared__ __attribute__((aligned(16))) __bf16 xs[G::PLANES * G::PLANE];
     __shared__ __attribute__((aligned(16))) float cst[MAX_LAYERS * CST_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63;
+    // persistent workgroups walking the row list, as in the fp32 kernel (dan_kernels.hip)
+    typedef const __attribute__((address_space(4))) Segment16Args* kernarg_ptr;
+    auto row_body = [&](int wk, const auto& a) {
+    [[maybe_unused]] const int stamp_row = wk;
+    int tid = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int site = blockIdx.x / a.R, r = blockIdx.x - site * a.R;
+    const int row_index = __builtin_amdgcn_readfirstlane(a.work_count ? a.work[wk] : wk);     // uniform: everything derived stays scalar
+    const int site = row_index / a.R, r = row_index - site * a.R;
     const int L = a.L;
     const size_t read_idx = (size_t)site * a.R + r;
-    if (a.row_src && a.row_src[read_idx] != (int)read_idx) return;      // an empty duplicate (see launch_row_map)
     float* yrow = a.y + read_idx * (size_t)L * CPAD;
     const int pos = lane & 15, kq = lane >> 4;
     int chb[NT16];
@@ -406,13 +414,36 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
     STAMP16(62);
     copy_out16<SPLIT, MT>(xs, yrow, L, tid);
     STAMP16(63);
+    };   // row_body
+    if constexpr (PERSIST) {
+        const int n_work = a_by_value.work_count ? *a_by_value.work_count : a_by_value.n_rows;
+        for (int wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+            // arguments re-read per row through an opaque kernarg pointer (see the fp32 kernel)
+            kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ap));
+            row_body(wk, *ap);
+            __syncthreads();                                // the next row re-uses the LDS image
+        }
+    } else {
+        // one workgroup per row; with a row list there may be fewer rows than workgroups
+        if (!a_by_value.work_count || (int)blockIdx.x < *a_by_value.work_count) row_body((int)blockIdx.x, a_by_value);
+    }
 }
 
-void launch_segment16(const Segment16Args& a, int n_sites, int precision, hipStream_t s) {
-    const dim3 grid((unsigned)(n_sites * a.R)), blk(SEG_THREADS);
-    if (precision == 1) hipLaunchKernelGGL((segment16_kernel<true, 13>), grid, blk, 0, s, a);
-    else if (a.L <= 13 * 16) hipLaunchKernelGGL((segment16_kernel<false, 13>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((segment16_kernel<false, 19>), grid, blk, 0, s, a);
+void launch_segment16(const Segment16Args& a0, int n_sites, int precision, int max_wgs, hipStream_t s) {
+    Segment16Args a = a0;
+    a.n_rows = n_sites * a.R;
+    const bool persist = a.work_count != nullptr && max_wgs > 0 && max_wgs < a.n_rows;
+    const dim3 grid((unsigned)(persist ? max_wgs : a.n_rows)), blk(SEG_THREADS);
+    if (persist) {
+        if (precision == 1) hipLaunchKernelGGL((segment16_kernel<true, 13, true>), grid, blk, 0, s, a);
+        else if (a.L <= 13 * 16) hipLaunchKernelGGL((segment16_kernel<false, 13, true>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((segment16_kernel<false, 19, true>), grid, blk, 0, s, a);
+    } else {
+        if (precision == 1) hipLaunchKernelGGL((segment16_kernel<true, 13, false>), grid, blk, 0, s, a);
+        else if (a.L <= 13 * 16) hipLaunchKernelGGL((segment16_kernel<false, 13, false>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((segment16_kernel<false, 19, false>), grid, blk, 0, s, a);
+    }
 }
 
 }  // namespace dan

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     q.res_mask = a.res_mask; q.has_hw = 1; q.R = R; q.L = L; q.reads = q.qual = q.strand = q.ref = q.ref_mask = q.var_mask = d_u8;
     q.emb = d_emb; q.pe = d_pe; q.y = d_y; q.pool = a.pool; q.h = d_h; q.h_layer_stride = a.h_layer_stride; q.tap = nullptr; q.tap_layer = -1;
     for (int rep = 0; rep < 3; ++rep) {
-        if (precision == 0) launch_segment(a, sites, 0, 0); else launch_segment16(q, sites, precision, 0);
+        if (precision == 0) launch_segment(a, sites, 0, 0); else launch_segment16(q, sites, precision, 0, 0);
         CK(hipDeviceSynchronize());
     }
     std::vector<unsigned long long> st(nst);
