@@ -127,6 +127,19 @@ def test_config1_plumbing_end_to_end(hdf_1k, tmp_path):
     called = vcf.format_vcf_lines([l + "\n" for l in lines], vcf.FormatOptions(**vcf.PIPELINE_OPTIONS))
     gts = [l.rstrip("\n").split("\t")[-1].split(":")[0] for l in called if not l.startswith("#")]
     assert set(gts) <= {"0/1", "1/1"} and len(gts) <= 1000
+    # ... and the last five commands of the pipeline in process (join, rewrites, bgzip, tabix), on the same file
+    import gzip
+    from dl4vc_amd import vcfpost
+    thres = tmp_path / "model_test_sorted_thres.vcf"
+    thres.write_text("".join(called))
+    vcfpost.finish_calls(str(thres), str(tmp_path / "join.vcf"), str(tmp_path / "called_variants.vcf.gz"))
+    joined = open(tmp_path / "join.vcf").read()
+    assert gzip.open(tmp_path / "called_variants.vcf.gz", "rt").read() == joined
+    recs_out = [l for l in joined.splitlines() if not l.startswith("#")]
+    assert len(recs_out) == len({(l.split("\t")[0], l.split("\t")[1]) for l in recs_out})        # one record per position
+    if recs_out:
+        first = recs_out[0].split("\t")
+        assert vcfpost.tabix_query(str(tmp_path / "called_variants.vcf.gz"), first[0], int(first[1]), int(first[1])) == [recs_out[0]]
 
 
 def test_shard_ranges_cover_exactly():
