@@ -110,6 +110,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
  * "feature" [B][feature_stride], "hidden0" [B][fc0], "hidden1" [B][fc1]; returns the number of floats
  * copied (<= capacity) or a negative status.  dan_query(): integer facts by name ("feature_width",
  * "feature_stride", "chunk_sites", "max_batch", "cpad", "tap_sites"). */
+/* (With skip_empty_rows = 1 the tap and "y" rows of skipped empty pileup rows are not written: read their source row.) */
 int dan_set_tap(dan_t* h, int32_t layer);
 int64_t dan_read_buffer(dan_t* h, const char* name, float* dst, int64_t capacity);
 int64_t dan_query(const dan_t* h, const char* what);
