@@ -20,6 +20,7 @@
 extern "C" {
 #endif
 
+/* ABI history: 1 = first release; 2 = dan_config.conv_algo; 3 = dan_config.skip_empty_rows (struct grows at the end). */
 #define DAN_ABI_VERSION 3
 #define DAN_MAX_LAYERS 16
 
