@@ -104,6 +104,13 @@ def test_production_shape_against_oracle(reads):
         close(got[k], want[k], SCORE_ATOL, k)
     close(got["vt_logits"], want["vt_logits"], TAP_RTOL, "vt_logits")
     net.close()
+    # the production CLI default: empty pileup rows computed once per site -- same bits
+    import dataclasses
+    net = DanNet(dataclasses.replace(cfg, skip_empty_rows=True)).load_state_dict(sd)
+    again = net.forward_u8(*batch.arrays())
+    for k in got:
+        assert np.array_equal(got[k], again[k]), k
+    net.close()
 
 
 def test_chunk_and_batch_boundaries_do_not_change_results():
