@@ -68,6 +68,7 @@ struct SegmentArgs {
     int tap_layer;               // 0 = encoded input, l = after conv layer l (1-based), -1 = none
     int wino;                    // 1: dilation-2 layers after the first run in Winograd F(2,3) form
     int n_rows;                  // filled by launch_segment: n_sites * R
+    int xcd_rows;                // filled by launch_segment: rows per XCD slice (whole sites)
     const int* work;             // rows to compute (device list, see launch_row_map); read only when work_count is set
     const int* work_count;       // length of that list (device) or nullptr = every row
 };

@@ -294,8 +294,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     // (the row body sits at function scope with an explicit back edge: wrapped in a lambda, or in a for loop left by a
     // compile-time break, the same code costs the non-persistent form 56 spilled registers)
     const int n_work = a_by_value.work_count ? *a_by_value.work_count : a_by_value.n_rows;
-    int wk = blockIdx.x;
-    if (wk >= n_work) return;
+    // XCD-aware order: workgroups b and b + 8 share an XCD (round-robin dealing), so the rows are cut into 8 contiguous
+    // slices of `per` rows and workgroup b takes row (b % 8) * per + b / 8 (+ a multiple of the grid's eighth when
+    // persistent): the 64 reads of a site, which all read that site's pool image and the same weights, stay in one L2.
+    const int per = a_by_value.work_count ? (n_work + 7) >> 3 : a_by_value.xcd_rows;
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;                                // position inside the XCD's slice
+    int wk = xcd * per + j;
+    if (j >= per || wk >= n_work) return;
 next_row:                                                   // (PERSIST only: back edge at the bottom)
     {
     // PERSIST: the arguments are re-read from the kernarg segment for every row through a pointer the compiler cannot see
@@ -706,17 +712,19 @@ next_row:                                                   // (PERSIST only: ba
     STAMP(63);
     }
     if constexpr (PERSIST) {
-        wk += gridDim.x;
+        j += gridDim.x >> 3;
+        wk = xcd * per + j;
         __syncthreads();                                    // the next row re-uses the LDS image
-        if (wk < n_work) goto next_row;
+        if (j < per && wk < n_work) goto next_row;
     }
 }
 
 void launch_segment(const SegmentArgs& a0, int n_sites, int max_wgs, hipStream_t s) {
     SegmentArgs a = a0;
     a.n_rows = n_sites * a.R;
-    const bool persist = a.work_count != nullptr && max_wgs > 0 && max_wgs < a.n_rows;
-    const dim3 grid((unsigned)(persist ? max_wgs : a.n_rows)), blk(SEG_THREADS);
+    a.xcd_rows = ((n_sites + 7) / 8) * a.R;                 // whole sites per XCD slice
+    const bool persist = a.work_count != nullptr && max_wgs >= 8 && max_wgs < a.n_rows;
+    const dim3 grid((unsigned)(persist ? (max_wgs & ~7) : 8 * a.xcd_rows)), blk(SEG_THREADS);
     if (persist) {
         if (a.wino) hipLaunchKernelGGL((segment_kernel<true, true>), grid, blk, 0, s, a);
         else hipLaunchKernelGGL((segment_kernel<false, true>), grid, blk, 0, s, a);
