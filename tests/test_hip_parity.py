@@ -264,3 +264,33 @@ def test_skipping_empty_rows_is_bit_identical(precision, algo):
         net.close()
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_structures_all_forms_agree(seed):
+    """Seeded random structures (reads, window, layers, pools, residual start, widths): the Winograd form, the direct form
+    and the skip-empty-rows form agree with the oracle and with each other."""
+    import dataclasses
+    rng = np.random.default_rng(1000 + seed)
+    layers = int(rng.integers(2, 8))
+    pools = tuple(sorted(set(int(p) for p in rng.integers(1, layers, size=int(rng.integers(0, 3))) if 1 <= p < layers)))
+    res = int(rng.choice([0] + list(range(2, layers + 1))))
+    kw = dict(reads=int(rng.integers(1, 40)), length=int(rng.integers(112, 209)), layers=layers, pool_layers=pools,      # (the allele sits at column 100)
+              residual_start=res, c_init=int(rng.choice([16, 48, 128])), c_final=int(rng.choice([16, 48, 128])),
+              bottleneck=int(rng.choice([0, 8, 32])), fc_sizes=(32, 16), use_bn=bool(rng.integers(0, 2)),
+              use_q=bool(rng.integers(0, 2)), use_strand=bool(rng.integers(0, 2)), use_mask=bool(rng.integers(0, 2)))
+    cfg = DanConfig(**kw)
+    sd = random_state_dict(cfg, seed=2000 + seed)
+    batch = synth.make_sites(int(rng.integers(1, 7)), reads=cfg.reads, length=cfg.length, seed=3000 + seed)
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    outs = {}
+    for tag, c in (("winograd", cfg), ("direct", dataclasses.replace(cfg, conv_algo=1)),
+                   ("skip", dataclasses.replace(cfg, skip_empty_rows=True))):
+        net = DanNet(c).load_state_dict(sd)
+        outs[tag] = got = net.forward_u8(*batch.arrays(), aux=True)
+        net.close()
+        for k in ("vt_prob", "bp"):
+            close(got[k], want[k], SCORE_ATOL, "%s %s %s" % (kw, tag, k))
+        close(got["vt_logits"], want["vt_logits"], TAP_RTOL, "%s %s vt_logits" % (kw, tag))
+    for k in outs["winograd"]:
+        assert np.array_equal(outs["winograd"][k], outs["skip"][k]), k
