@@ -38,12 +38,12 @@ def cpu_baseline(cfg, sd, batch, budget_s=20.0):
     # pool across all 256 visible threads is slower than using the share
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    n = 8
+    n = 32                                                   # ~2 s per pass on 16 threads: 10-15 s of CPU work in all
     arrays = [a[:n] for a in batch.arrays()]
     t0 = time.perf_counter()
     dan_forward_oracle(sd, cfg, *arrays)                      # warm-up (also sizes the sample)
     warm = time.perf_counter() - t0
-    reps = int(max(1, min(8, (budget_s - warm) // max(warm, 1e-3))))
+    reps = int(max(1, min(5, (budget_s - warm) // max(warm, 1e-3))))
     best = None
     for _ in range(reps):
         t0 = time.perf_counter()
