@@ -56,7 +56,7 @@ typedef struct dan_config {
                                * product, L <= 208); 2 = plain bf16 (L <= 304, BASELINE config 5)   */
     int32_t device_id;        /* HIP device ordinal                                               */
     int32_t max_batch;        /* sites per FC macro-batch (0 = 4096)                              */
-    int32_t chunk_sites;      /* sites per conv-stack chunk (0 = 128)                             */
+    int32_t chunk_sites;      /* sites per conv-stack chunk (0 = largest power of two with y + h under 48 GB) */
     int32_t conv_algo;        /* fp32 path, form of the 3-tap convolutions after the first layer: 1 = direct implicit
                                * GEMM; 2 = Winograd F(2,3) over the dilated positions (needs every such layer to
                                * have dilation 2: 4 exact-fp32 GEMMs per 2 outputs instead of 6); 0 = Winograd

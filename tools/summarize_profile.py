@@ -64,8 +64,6 @@ def main():
             ev, od = d[0::2], d[1::2]
             out.write("# %s,%d,%.0f,%.0f,%.0f\n" % (k, len(d), sum(d) / len(d), sum(ev) / max(len(ev), 1), sum(od) / max(len(od), 1)))
     line = [l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1]
-    with open(os.path.join(dst, tag + "_bench_line_under_rocprof.json"), "w") as out:
-        out.write(line)
 
     # ---- HBM traffic
     traffic = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
@@ -87,14 +85,20 @@ def main():
     fetch = 2.0 * seg_bytes["FETCH_SIZE"]
     traffic["segment_kernel_bytes_per_launch"] = {"fetch_corrected": fetch, "write": seg_bytes["WRITE_SIZE"],
                                                   "total": fetch + seg_bytes["WRITE_SIZE"]}
-    R, L, S = 64, 201, 128
+    n_disp = max(d["dispatches"] for k, d in traffic["per_kernel"]["WRITE_SIZE"].items() if "segment_kernel" in k)
+    R, L, S = 64, 201, 4096 * 2 // n_disp                     # the PMC bench runs 4096 sites, 2 segment launches per chunk
     y = S * R * L * 128 * 4
     algo = (S * (3 * R * L + 3 * L) + 3 * y + 7 * S * R * L * 32 * 4 + S * L * 128 * 4) / 2.0
     traffic["segment_kernel_algorithmic_bytes_per_launch"] = {
-        "note": "chunk of 128 sites x 64 reads x 201: uint8 inputs + y2 write + y2 read + pool read + y7 write + bottleneck outputs "
-                "h 7 x 210.8 MB, averaged over the two launches of a chunk", "total": algo}
+        "note": "chunk of %d sites x 64 reads x 201: uint8 inputs + y2 write + y2 read + pool read + y7 write + bottleneck outputs h "
+                "(7 layers), averaged over the two launches of a chunk" % S, "total": algo}
     with open(os.path.join(dst, tag + "_traffic.json"), "w") as out:
         json.dump(traffic, out, indent=1)
+    # the profiled run printed its line before these counters existed: carry the traffic measured for the same command
+    rec = json.loads(line)
+    rec["roofline"]["traffic"] = int(fetch + seg_bytes["WRITE_SIZE"])
+    with open(os.path.join(dst, tag + "_bench_line_under_rocprof.json"), "w") as out:
+        out.write(json.dumps(rec) + "\n")
 
     # ---- SQ counters
     rows = defaultdict(dict)
