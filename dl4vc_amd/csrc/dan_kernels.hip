@@ -821,13 +821,14 @@ void launch_read_mean(const float* y, float* pool, int n_sites, int R, int L, co
 
 __global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__ y, float* __restrict__ feat,
                                                          long long fs, int R, int L, int C, const int* __restrict__ row_src) {
-    __shared__ float tmax[CPAD * 17], tavg[CPAD * 17];
+    constexpr int PT = 32, PS = PT + 1;                        // 32 positions per workgroup: 128-byte runs in the feature row
+    __shared__ float tmax[CPAD * PS], tavg[CPAD * PS];
     const int pt = blockIdx.x, site = blockIdx.y, tid = threadIdx.x;
     const int c4 = tid & 31, pl = tid >> 5;
     const int n4 = L * (CPAD / 4);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int pp = half * 8 + pl, p = pt * 16 + pp;
+    for (int half = 0; half < PT / 8; ++half) {
+        const int pp = half * 8 + pl, p = pt * PT + pp;
         v4f mx = splat(0.f), av = splat(0.f);
         if (p < L) {
             const size_t off = (size_t)p * (CPAD / 4) + c4;
@@ -846,24 +847,24 @@ __global__ __launch_bounds__(256) void final_pool_kernel(const v4f* __restrict__
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tmax[(c4 * 4 + j) * 17 + pp] = mx[j];
-            tavg[(c4 * 4 + j) * 17 + pp] = av[j];
+            tmax[(c4 * 4 + j) * PS + pp] = mx[j];
+            tavg[(c4 * 4 + j) * PS + pp] = av[j];
         }
     }
     __syncthreads();
     float* row = feat + (size_t)site * fs;
-    for (int idx = tid; idx < CPAD * 16; idx += 256) {
-        const int c = idx >> 4, pp = idx & 15, p = pt * 16 + pp;
+    for (int idx = tid; idx < CPAD * PT; idx += 256) {
+        const int c = idx / PT, pp = idx % PT, p = pt * PT + pp;
         if (c < C && p < L) {
-            row[(size_t)c * L + p] = tmax[c * 17 + pp];                         // max block first (model.py:833)
-            row[(size_t)C * L + (size_t)c * L + p] = tavg[c * 17 + pp];
+            row[(size_t)c * L + p] = tmax[c * PS + pp];                         // max block first (model.py:833)
+            row[(size_t)C * L + (size_t)c * L + p] = tavg[c * PS + pp];
         }
     }
 }
 
 void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, int R, int L, int C, const int* row_src,
                        hipStream_t s) {
-    hipLaunchKernelGGL(final_pool_kernel, dim3((L + 15) / 16, n_sites), dim3(256), 0, s, (const v4f*)y, feat, fs, R, L, C,
+    hipLaunchKernelGGL(final_pool_kernel, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const v4f*)y, feat, fs, R, L, C,
                        row_src);
 }
 
