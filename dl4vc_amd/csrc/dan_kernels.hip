@@ -875,7 +875,7 @@ void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, i
 // tiles are summed through LDS in fixed wave order (deterministic).
 // ------------------------------------------------------------------------------------------------
 constexpr int HW_WAVES = 8;
-constexpr int HW_RT = 2;                                    // 16-read row tiles per workgroup (weights amortised over 32 reads)
+constexpr int HW_RT = 4;                                    // 16-read row tiles per workgroup (weights amortised over 64 reads; 8 tiles spill)
 __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ h, long long hls,
                                                       const v4f* __restrict__ wc, long long wcls,
                                                       const float* __restrict__ bc, float* __restrict__ feat,
