@@ -264,6 +264,9 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         while (chunk * 2 <= h->max_batch && (double)(chunk * 2) * per_site <= 48e9) chunk *= 2;
         h->chunk = chunk;
     }
+    // the read-axis reductions put the chunk's site index in gridDim.y (limit 65 535): no chunk exceeds 32 768 sites,
+    // whatever the caller or the automatic sizing asks for (results do not depend on the chunking)
+    h->chunk = std::min(h->chunk, 32768);
     h->wino = wino_ok && c.conv_algo != 1;
     h->max_batch = ((h->max_batch + h->chunk - 1) / h->chunk) * h->chunk;
     h->F = 2 * c.c_final * c.length + c.layers * c.bottleneck * c.reads;
@@ -534,6 +537,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
                     launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
                     rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
+                    HIPCHK(h, hipGetLastError());            // a refused launch must not let garbage flow on to the FC
                 }
             }
             float* feat = h->d_feat + (size_t)c0 * h->F_stride;
@@ -541,6 +545,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
             int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
             launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
+            HIPCHK(h, hipGetLastError());
             if (H > 0) {
                 rc = prof_begin(h, "highway", s, &ev); if (rc) return rc;
                 launch_highway(h->d_h, h_layer_stride, h->d_wc, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat, h->F_stride,

@@ -349,6 +349,16 @@ std::unique_ptr<Batch> build_batch(dl_loader* l, int64_t b) {
             out->error = buf;
             return out;
         }
+        if (k < R && num_reads > k) {
+            // a pileup so deep that the stored window [start, start + store) runs past the stored rows (num_reads > 2 x
+            // store): the reference yields a (L, k) item here and its DataLoader cannot collate it (dataset.py:517-521,
+            // :270-281).  Same behaviour in the Python twin (dl4vc_amd/dataset.py::assemble_site): refuse, name the record.
+            char buf[200];
+            snprintf(buf, sizeof buf, "record %lld: num_reads %d leaves %d stored rows in the sampling window (< %d reads): "
+                     "the reference cannot batch this site either", (long long)(first + i), num_reads, k, R);
+            out->error = buf;
+            return out;
+        }
         for (int r = 0; r < k; ++r) {
             const size_t src = (size_t)(start + rows[r]) * L, dst = (size_t)i * rl + (size_t)r * L;
             memcpy(&out->reads[dst], rec + l->off_reads + src, L);
@@ -426,6 +436,9 @@ int dl_open(const char* path, const char* libhdf5_path, int32_t reads, int64_t l
     l->did = h.Dopen2(l->fid, "data", 0);
     if (l->did < 0) { h.Fclose(l->fid); return fail_open("%s has no dataset 'data'", path); }
     l->tid = h.Dget_type(l->did);
+    // every error return below closes the type / dataset / file handles (the dlopen'ed libhdf5 is reference-counted by
+    // the dynamic loader and deliberately never dlclose'd: it registers atexit handlers)
+    auto close_all = [&]() { if (l->tid >= 0) h.Tclose(l->tid); h.Dclose(l->did); h.Fclose(l->fid); l->tid = l->did = l->fid = -1; };
     l->itemsize = h.Tget_size(l->tid);
     hid_t sp = h.Dget_space(l->did);
     hsize_t dims[1] = {0};
@@ -440,14 +453,16 @@ int dl_open(const char* path, const char* libhdf5_path, int32_t reads, int64_t l
     };
     if (!(off("single_reads", l->off_reads) && off("ref_bases", l->off_ref) && off("num_reads", l->off_num) &&
           off("vcfrec", l->off_vcf) && off("q-scores", l->off_q) && off("strand", l->off_strand))) {
-        h.Dclose(l->did); h.Fclose(l->fid);
+        close_all();
         return fail_open("%s: record type lacks a field of the converter schema", path);
     }
     l->L = 201;
     // packed layout: ref_bases follows single_reads (tools/convert_bam_single_reads.py:694-698)
     l->store_rows = (int)((l->off_ref - l->off_reads) / l->L);
-    if (l->store_rows < 1 || (l->off_ref - l->off_reads) % l->L || l->off_strand - l->off_q != (size_t)l->store_rows * l->L)
+    if (l->store_rows < 1 || (l->off_ref - l->off_reads) % l->L || l->off_strand - l->off_q != (size_t)l->store_rows * l->L) {
+        close_all();
         return fail_open("%s: unexpected record layout", path);
+    }
     hid_t pl = h.Dget_create_plist(l->did);
     if (pl >= 0) {
         if (h.Pget_layout(pl) == 2 /*H5D_CHUNKED*/) {

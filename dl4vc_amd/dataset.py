@@ -71,6 +71,12 @@ def assemble_site(record, max_reads: int, rng=None, use_q: bool = True, use_stra
     if rng is not None:
         rng.random_sample()          # the reference's disabled dynamic-down-sampling coin (dataset.py:531)
     rows = select_rows(num_reads, rows_all.shape[0], max_reads, rng)
+    if len(rows) < max_reads and num_reads > len(rows):
+        # num_reads > 2 x stored rows: the window [start, start + store) runs past the stored rows and fewer than
+        # max_reads remain.  The reference yields a (L, k) item its DataLoader cannot collate (dataset.py:517-521,
+        # :270-281); the native loader (csrc/dan_loader.cpp::build_batch) refuses the same way.
+        raise ValueError("num_reads %d leaves %d stored rows in the sampling window (< %d reads): the reference cannot "
+                         "batch this site either" % (num_reads, len(rows), max_reads))
     reads = np.ascontiguousarray(rows_all[rows])
     if use_q:
         qual = np.ascontiguousarray(np.asarray(record["q-scores"], np.uint8)[start:start + store_max_reads][rows])

@@ -159,6 +159,32 @@ class CandidateFile:
             raise OSError("H5Dread failed on %s[%d:%d]" % (self.path, lo, hi))
         return out
 
+    def read_field(self, lo: int, hi: int, name: str) -> np.ndarray:
+        """One member of records ``[lo, hi)`` (e.g. ``vcfrec``) without materialising the 124-KB records: the memory type
+        handed to H5Dread is a compound holding only that member, libhdf5 extracts it while it inflates the chunks."""
+        lo, hi = max(0, int(lo)), min(int(hi), self._n)
+        n = max(0, hi - lo)
+        if self._h5 is not None:
+            return self._d.fields(name)[lo:hi]
+        ft = self._dtype.fields[name][0]
+        sub = np.dtype([(name, ft)])
+        out = np.empty(n, dtype=sub)
+        if n == 0:
+            return out[name]
+        lib = self._lib
+        mt = _h5_compound_type(lib, sub)
+        fs = lib.H5Dget_space(self._did)
+        start, count = (hsize_t * 1)(lo), (hsize_t * 1)(n)
+        lib.H5Sselect_hyperslab(fs, H5S_SELECT_SET, start, None, count, None)
+        ms = lib.H5Screate_simple(1, count, None)
+        rc = lib.H5Dread(self._did, mt, ms, fs, 0, out.ctypes.data_as(C.c_void_p))
+        lib.H5Sclose(ms)
+        lib.H5Sclose(fs)
+        lib.H5Tclose(mt)
+        if rc < 0:
+            raise OSError("H5Dread(%s) failed on %s[%d:%d]" % (name, self.path, lo, hi))
+        return out[name]
+
     def close(self):
         if self._h5 is not None:
             self._f.close()

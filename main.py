@@ -23,6 +23,21 @@ sys.path.insert(0, ROOT)
 from arguments import create_arg_parser                       # noqa: E402
 
 
+def child_devices(n: int):
+    """HIP_VISIBLE_DEVICES value of each of the ``n`` shard processes: the g-th entry of the PARENT's device mask
+    (HIP_VISIBLE_DEVICES, else CUDA_VISIBLE_DEVICES, which HIP honours too), or plain g without a mask.  A
+    ROCR_VISIBLE_DEVICES mask needs no handling: HIP indices are already relative to it and the children inherit it."""
+    if os.environ.get("DL4VC_FORCE_DEVICE0"):                 # rehearse the multi-process path on a one-GPU box (tests)
+        return ["0"] * n
+    mask = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
+    if mask is None:
+        return [str(g) for g in range(n)]
+    have = [d.strip() for d in mask.split(",") if d.strip()]
+    if len(have) < n:
+        raise SystemExit("--gpus %d but the device mask '%s' lists only %d device(s)" % (n, mask, len(have)))
+    return have[:n]
+
+
 def main(argv=None) -> int:
     args = create_arg_parser().parse_args(argv)
     print(args)
@@ -44,6 +59,15 @@ def main(argv=None) -> int:
     cfg = dataclasses.replace(cfg, precision=("fp32", "bf16x3", "bf16").index(args.precision),
                               conv_algo=("auto", "direct", "winograd").index(args.conv_algo),
                               skip_empty_rows=not args.compute_empty_rows)
+    # Data-path flags that change WHICH sites reach the VCF: honoured or refused, never silently ignored.
+    if args.shuffle_test:
+        # main.py:90-92: DataLoader(shuffle=True) / an unseeded np.random.permutation -- the reference's order is not
+        # reproducible and call_variants.sh sorts the records afterwards (:151); the set of sites is unchanged
+        raise SystemExit("--shuffle_test is not supported: the reference's shuffled order is unseeded and the pipeline sorts "
+                         "the scored records anyway (call_variants.sh:151); drop the flag")
+    holdout = tuple(str(c) for c in (args.test_holdout_chromosomes or ()))
+    # trainer.py:513-515: the loop breaks when batch > max_test_batches, batches of --test-batch-size sites
+    site_limit = (args.max_test_batches + 1) * args.test_batch_size if args.max_test_batches > 0 else 0
     shard_i, shard_n = parse_shard(args.shard)
     if args.save_vcf_records:
         assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"
@@ -54,14 +78,19 @@ def main(argv=None) -> int:
         # one process per GPU, contiguous shards, host-side concat
         t0 = time.time()
         procs = []
+        devices = child_devices(args.gpus)
         for g in range(args.gpus):
-            # DL4VC_FORCE_DEVICE0: rehearse the multi-process path on a one-GPU box (tests)
-            dev = "0" if os.environ.get("DL4VC_FORCE_DEVICE0") else str(g)
-            env = dict(os.environ, HIP_VISIBLE_DEVICES=dev, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=devices[g], HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.pop("CUDA_VISIBLE_DEVICES", None)             # (HIP honours both; the mask is carried in HIP_VISIBLE_DEVICES)
             cmd = [sys.executable, os.path.abspath(__file__)] + list(argv or sys.argv[1:]) + ["--shard", "%d/%d" % (g, args.gpus)]
             procs.append(subprocess.Popen(cmd, env=env))
         rcs = [p.wait() for p in procs]
         if any(rcs):
+            for g in range(args.gpus):                        # no half-written parts left behind
+                try:
+                    os.remove(part_path(out_final, g))
+                except OSError:
+                    pass
             raise SystemExit("shard process failed: %s" % rcs)
         concat_parts(out_final, args.gpus, header_from=args.sample_vcf)
         print("\tTime elapsed for inference/testing {:.4f}".format(time.time() - t0))
@@ -79,7 +108,7 @@ def main(argv=None) -> int:
         target = out_final + ".records"
     n = run_shard(net, args.test_file, target, shard_i, shard_n, sites_per_launch=args.sites_per_launch,
                   reads_seed=args.reads_seed, use_var_type_threshold=args.use_var_type_threshold,
-                  max_batches=args.max_test_batches, log=lambda m: print(m, end="\r"))
+                  holdout_chromosomes=holdout, site_limit=site_limit, log=lambda m: print(m, end="\r"))
     net.close()
     if shard_n == 1:
         if args.sample_vcf:

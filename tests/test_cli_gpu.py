@@ -71,3 +71,32 @@ def test_main_py_inference(tmp_path, gpus):
         s = _scores(line)
         assert abs(s[0] - want_bp[i]) < 1e-4 and np.abs(s[1:] - want_vt[i]).max() < 1e-4, (i, s, want_bp[i], want_vt[i])
         assert line.split("\t")[1] == batch.vcfrec[i].split("\t")[1]
+
+
+def test_bench_two_rank_launch_path():
+    """The N > 1 branch of bench.py exactly as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed
+    on a one-GPU box: both ranks on device 0, gloo instead of RCCL for the barrier and the max of the elapsed times (RCCL
+    refuses two ranks on one device).  Sites shard with no data-path collective: main.py:117 / SURVEY.md section 8e."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_FORCE_DEVICE0="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sites", "512", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--no-skip-pass"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 1
+    assert rec["config"]["sites_per_gpu"] == 512 and rec["config"]["parallelism"] == "site-shard x2"
+    # whole-job aggregate: both ranks' sites over the max-over-ranks time
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 1024) < 1.0
+    assert rec["parity"]["ok"] and rec["parity"]["tiled_identical"] and rec["parity"]["oracle_sites"] == 32
+    assert "cpu_baseline" not in rec
+    ranks = [l for l in r.stderr.splitlines() if l.startswith("[bench rank")]
+    assert len(ranks) == 2 and any("rank 0/2" in l for l in ranks) and any("rank 1/2" in l for l in ranks)

@@ -181,6 +181,67 @@ def test_two_rank_sharding_equals_single_process(hdf_1k, tmp_path):
     assert not os.path.exists(part_path(multi, 0))
 
 
+def test_holdout_chromosomes_and_site_limit_select_the_reference_sites(tmp_path):
+    """--test_holdout_chromosomes tests ONLY those chromosomes (dataset.py:382-395, :706-711, main.py:88-92);
+    --max-test-batches N --test-batch-size S visits (N + 1) * S sites (trainer.py:513-515).  Shards split the SELECTED
+    sites; the read-subset seed stays tied to the absolute record index."""
+    from dl4vc_amd.inference import select_sites, index_runs
+    batch = synth.make_sites(60, reads=8, seed=5)
+    recs = hdf5io.records_from_sites(batch, store_reads=200)
+    chroms = ["chr1"] * 20 + ["chr20"] * 15 + ["chr2"] * 10 + ["chr20"] * 5 + ["20"] * 10
+    for i, c in enumerate(chroms):
+        f = batch.vcfrec[i].split("\t")
+        f[0], f[1] = c, str(1000 + i)
+        recs[i]["vcfrec"] = "\t".join(f).encode()
+    path = str(tmp_path / "c.hdf")
+    hdf5io.write_candidates(path, recs)
+    with hdf5io.CandidateFile(path) as f:
+        col = f.read_field(18, 23, "vcfrec")
+        assert [bytes(v).split(b"\t")[0] for v in col] == [b"chr1", b"chr1", b"chr20", b"chr20", b"chr20"]
+    assert select_sites(path).tolist() == list(range(60))
+    sel = select_sites(path, ["chr20"])
+    assert sel.tolist() == list(range(20, 35)) + list(range(45, 50))          # exact string match: '20' is another name
+    assert index_runs(sel) == [(20, 35), (45, 50)]
+    assert select_sites(path, ["chr20", "20"], site_limit=22).tolist() == list(range(20, 35)) + list(range(45, 50)) + [50, 51]
+    assert select_sites(path, site_limit=7).tolist() == list(range(7))
+    assert index_runs(np.zeros(0, np.int64)) == []
+    net = OracleNet(SMALL, random_state_dict(SMALL, seed=2))
+    full = str(tmp_path / "full.vcf")
+    assert run_shard(net, path, full, sites_per_launch=1000) == 60
+    body = open(full).read().splitlines()
+    held = str(tmp_path / "held.vcf")
+    assert run_shard(net, path, held, holdout_chromosomes=("chr20",), sites_per_launch=1000) == 20
+    got = open(held).read().splitlines()
+    assert [l.split("\t")[1] for l in got] == [str(1000 + i) for i in sel]
+    sc = lambda l: np.array([float(kv.split("=")[1]) for kv in l.split("\t")[2].split(";")])   # noqa: E731
+    assert max(np.abs(sc(a) - sc(body[i])).max() for a, i in zip(got, sel)) < 1e-5
+    # two shards of the selection, concatenated
+    for g in range(2):
+        run_shard(net, path, part_path(held, g), g, 2, holdout_chromosomes=("chr20",), sites_per_launch=1000)
+    both = open(part_path(held, 0)).read().splitlines() + open(part_path(held, 1)).read().splitlines()
+    assert [l.split("\t")[1] for l in both] == [l.split("\t")[1] for l in got]
+    lim = str(tmp_path / "lim.vcf")
+    assert run_shard(net, path, lim, site_limit=(2 + 1) * 4, sites_per_launch=5) == 12     # --max-test-batches 2 --test-batch-size 4
+
+
+def test_main_refuses_shuffle_test_and_maps_device_mask(monkeypatch):
+    import sys
+    sys.path.insert(0, ROOT)
+    import main as cli
+    with pytest.raises(SystemExit, match="shuffle_test"):
+        cli.main(["--test_file", "x.hdf", "--modelload", "c.pt", "--shuffle_test", "--model_pool_combine_dimension", "0"])
+    monkeypatch.delenv("DL4VC_FORCE_DEVICE0", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    assert cli.child_devices(3) == ["0", "1", "2"]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,7")
+    assert cli.child_devices(2) == ["4", "5"]
+    with pytest.raises(SystemExit, match="lists only 3"):
+        cli.child_devices(4)
+    monkeypatch.setenv("DL4VC_FORCE_DEVICE0", "1")
+    assert cli.child_devices(2) == ["0", "0"]
+
+
 def test_cli_refuses_without_gpu(hdf_1k, tmp_path):
     import subprocess
     import sys

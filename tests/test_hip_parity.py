@@ -113,6 +113,39 @@ def test_production_shape_against_oracle(reads):
     net.close()
 
 
+def test_config2_real_batch_default_chunking():
+    """BASELINE config 2 at its real size: batch 4096 sites x 100 reads x 201 bp, production width, fp32, DEFAULT chunking
+    (1024-site chunks, 4096-site macro-batches; the XCD-aware row order of the segment kernel is only non-trivial here).
+    4608 sites = one full macro-batch + a partial one.  Eight distinct sites sit on chunk and macro-batch boundaries and
+    are held to the oracle; everything else is a 256-site tile and must come out bit-identical wherever it sits
+    (the reference scores a site independently of its batch position: main.py:94 shuffle=False, trainer.py:569-572)."""
+    cfg = DanConfig()                                            # production structure, R = 100
+    sd = random_state_dict(cfg, seed=7)
+    base = synth.make_sites(256, reads=100, seed=170)
+    extra = synth.make_sites(8, reads=100, seed=171)
+    B = 4608
+    spots = [0, 1023, 1024, 2047, 2048, 4095, 4096, 4607]
+    arrs = []
+    for a, e in zip(base.arrays(), extra.arrays()):
+        t = np.concatenate([a] * (B // 256), axis=0)
+        t[spots] = e
+        arrs.append(t)
+    net = DanNet(cfg).load_state_dict(sd)
+    assert net.handle.query("chunk_sites") == 1024 and net.handle.query("max_batch") == 4096
+    got = net.forward_u8(*arrs)
+    net.close()
+    want = dan_forward_oracle(sd, cfg, *extra.arrays())
+    for k in ("vt_prob", "bp"):
+        close(got[k][spots], want[k], SCORE_ATOL, "boundary sites " + k)
+    close(got["vt_logits"][spots], want["vt_logits"], TAP_RTOL, "boundary sites vt_logits")
+    keep = np.ones(B, bool)
+    keep[spots] = False
+    idx = np.arange(B)
+    for k in got:
+        tile = got[k][256 + idx % 256]                           # the second tile [256, 512) holds no replaced site
+        assert np.array_equal(got[k][keep], tile[keep]), "tiling property broken for " + k
+
+
 def test_chunk_and_batch_boundaries_do_not_change_results():
     """Sites are independent: any chunking of the same inputs gives bit-identical scores."""
     cfg = DanConfig(reads=8, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))

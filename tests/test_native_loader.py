@@ -81,6 +81,27 @@ def test_batches_equal_python_assembly(lib, tmp_path):
             list(nl)
 
 
+def test_very_deep_pileup_is_refused_by_both_paths(lib, tmp_path):
+    """num_reads > 2 x stored rows: the sampling window [start, start + 200) runs past the 200 stored rows (450 reads ->
+    start 125 -> 75 rows).  The reference yields a (201, 75) item its DataLoader cannot collate (dataset.py:517-521,
+    :270-281); here both loaders refuse and name the record instead of zero-padding silently."""
+    batch = synth.make_sites(5, reads=100, seed=3)
+    recs = hdf5io.records_from_sites(batch)
+    recs[3]["num_reads"] = 450
+    path = str(tmp_path / "deep.hdf")
+    hdf5io.write_candidates(path, recs)
+    with pytest.raises(ValueError, match="75 stored rows"):
+        assemble_batch(recs, 100, seed=5)
+    with loader.NativeLoader(path, reads=100, batch_sites=4, seed=5, threads=2) as nl:
+        with pytest.raises(ValueError, match="record 3: num_reads 450 leaves 75 stored rows"):
+            list(nl)
+    # R <= the rows that remain: both paths take the first... no: 450 > 64 draws a seeded subset of the 75 rows, identically
+    with loader.NativeLoader(path, reads=64, batch_sites=8, seed=5, threads=2) as nl:
+        (b,) = list(nl)
+    want = assemble_batch(recs, 64, seed=5)
+    np.testing.assert_array_equal(b.reads, want.reads)
+
+
 def test_reference_dataset_fixture_through_native_loader(lib, tmp_path):
     """tests/golden/dataset_a2.npz was produced by the reference's ContextDatasetFromNumpy (np.random.seed(1000+i))."""
     z = np.load(os.path.join(GOLDEN, "dataset_a2.npz"))
