@@ -108,6 +108,8 @@ def main():
                     help="skip the oracle's timing passes (its one pass used as the parity check of the timed outputs still runs "
                          "unless --no-oracle-check)")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the oracle comparison of the timed outputs")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="omit the informational host-buffer pass (first H2D to last D2H through dan_forward_async/dan_wait)")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 MFMA (headline), 1 bf16x3 split, 2 bf16")
     ap.add_argument("--window", type=int, default=201)
     ap.add_argument("--conv-algo", type=int, default=0, help="fp32 conv form: 0 auto (Winograd F(2,3) on the dilation-2 "
@@ -204,6 +206,36 @@ def main():
         cpu_line, want = cpu_baseline(cfg, sd, base, timing=(world == 1 and not args.no_cpu_baseline))
     parity = parity_check(outs, want, 256, cfg.precision)
 
+    # Informational (never `value`): SURVEY.md section 8d defines the metric from the first H2D to the last D2H.  One pass
+    # of the same batch from PAGEABLE host buffers through the double-buffered asynchronous ABI (pinned staging, H2D /
+    # forward / D2H on three streams), outputs checked bit-identical against the device-resident pass.
+    host_path = None
+    if world == 1 and not args.no_host_path:
+        host = [t.cpu().numpy() for t in planes]
+        mb = net.handle.query("max_batch")
+        got = {k: [] for k in ("bin_logits", "vt_logits", "vt_prob", "bp")}
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        prev = None
+        for b0 in range(0, B, mb):
+            tok = net.forward_u8_async(*[a[b0:b0 + mb] for a in host])
+            if prev is not None:
+                o = net.wait(prev)
+                for k in got:
+                    got[k].append(o[k])
+            prev = tok
+        o = net.wait(prev)
+        for k in got:
+            got[k].append(o[k])
+        eh = time.perf_counter() - th
+        same = all(np.array_equal(np.concatenate(got[k]), t.cpu().numpy())
+                   for k, t in zip(("bin_logits", "vt_logits", "vt_prob", "bp"), outs))
+        host_path = {"value": round(B / eh, 2), "unit": "candidate-variants/s", "sites": B,
+                     "definition": "first H2D to last D2H, pageable host inputs and outputs, %d-site batches through "
+                                   "dan_forward_async/dan_wait (pinned double-buffered staging)" % mb,
+                     "outputs_bit_identical_to_device_resident_pass": bool(same)}
+        del host, got
+
     # Informational second pass (never `value`): the same K steps with the all-padding pileup rows computed once per site
     # (dan_config.skip_empty_rows; outputs bit-identical).  The headline above computes every row, as the reference does.
     skip_value = None
@@ -278,12 +310,17 @@ def main():
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         line["parity"] = parity
+        if host_path is not None:
+            host_path["ratio_to_value"] = round(host_path["value"] / value, 4)
+            line["host_path"] = host_path
         print(json.dumps(line), flush=True)
     net.close()
     if dist is not None:
         dist.destroy_process_group()
     if not parity["ok"]:
         raise SystemExit("bench.py: outputs of the timed region failed the parity check: %s" % parity)
+    if host_path is not None and not host_path["outputs_bit_identical_to_device_resident_pass"]:
+        raise SystemExit("bench.py: the host-buffer pass disagrees with the device-resident pass")
 
 
 if __name__ == "__main__":

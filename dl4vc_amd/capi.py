@@ -16,11 +16,11 @@ from .config import DanConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdl4vc_dan.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/dl4vc_dan.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ("dan_abi_version", "dan_create", "dan_set_tensor", "dan_finalize", "dan_destroy", "dan_last_error",
-           "dan_forward", "dan_forward_aux", "dan_forward_device", "dan_set_tap", "dan_read_buffer", "dan_query",
+           "dan_forward", "dan_forward_aux", "dan_forward_device", "dan_forward_async", "dan_wait", "dan_set_tap", "dan_read_buffer", "dan_query",
            "dan_profile_enable", "dan_kernel_stats")
 
 
@@ -59,6 +59,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dan_forward.argtypes = [vp] + planes + [C.c_int64] + [vp] * 4
     lib.dan_forward_aux.argtypes = [vp] + planes + [C.c_int64] + [vp] * 5
     lib.dan_forward_device.argtypes = [vp] + planes + [C.c_int64] + [vp] * 5 + [vp]
+    lib.dan_forward_async.argtypes = [vp] + planes + [C.c_int64] + [vp] * 5 + [C.POINTER(C.c_int64)]
+    lib.dan_wait.argtypes = [vp, C.c_int64]
     lib.dan_set_tap.argtypes = [vp, C.c_int32]
     lib.dan_read_buffer.argtypes = [vp, C.c_char_p, f32p, C.c_int64]
     lib.dan_read_buffer.restype = C.c_int64
@@ -159,6 +161,33 @@ class DanHandle:
                                       p(out["aux"]) if aux else None)
         self._check(rc, "dan_forward")
         if aux:
+            a = out.pop("aux")
+            out.update(af=a[:, 0:1].copy(), cov=a[:, 1:2].copy(), vb=a[:, 2:12].copy(), vr=a[:, 12:22].copy())
+        return out
+
+    def forward_async(self, reads, qual, strand, ref, ref_mask, var_mask, aux: bool = False):
+        """Enqueue one batch (<= max_batch sites) on the double-buffered asynchronous path; returns a token for
+        ``wait``.  The input arrays are free again on return; at most two batches may be in flight."""
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        B = reads.shape[0]
+        R, L = self.cfg.reads, self.cfg.length
+        ins = [_u8(reads, (B, R, L), "reads"), _u8(qual, (B, R, L), "qual"), _u8(strand, (B, R, L), "strand"),
+               _u8(ref, (B, L), "ref"), _u8(ref_mask, (B, L), "ref_mask"), _u8(var_mask, (B, L), "var_mask")]
+        out = {"bin_logits": np.empty((B, 2), np.float32), "vt_logits": np.empty((B, 3), np.float32),
+               "vt_prob": np.empty((B, 3), np.float32), "bp": np.empty((B,), np.float32)}
+        if aux:
+            out["aux"] = np.empty((B, 22), np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        t = C.c_int64(-1)
+        rc = self.lib.dan_forward_async(self._h, *[p(a) for a in ins], B, p(out["bin_logits"]), p(out["vt_logits"]),
+                                        p(out["vt_prob"]), p(out["bp"]), p(out["aux"]) if aux else None, C.byref(t))
+        self._check(rc, "dan_forward_async")
+        return (int(t.value), out)                 # `out` keeps the destination arrays alive until wait()
+
+    def wait(self, token) -> Dict[str, np.ndarray]:
+        ticket, out = token
+        self._check(self.lib.dan_wait(self._h, ticket), "dan_wait")
+        if "aux" in out:
             a = out.pop("aux")
             out.update(af=a[:, 0:1].copy(), cov=a[:, 1:2].copy(), vb=a[:, 2:12].copy(), vr=a[:, 12:22].copy())
         return out

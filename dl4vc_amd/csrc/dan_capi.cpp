@@ -64,6 +64,17 @@ struct dan_handle {
     // staging for the host-pointer entry points
     uint8_t* d_in = nullptr;
     float* d_out = nullptr;
+    // asynchronous host-pointer path (dan_forward_async / dan_wait): two slots, allocated on first use
+    struct Slot {
+        uint8_t *pin_in = nullptr, *dev_in = nullptr;
+        float *pin_out = nullptr, *dev_out = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr;
+        int64_t ticket = -1, n = 0;
+        float* dst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    } slot[2];
+    bool async_ready = false;
+    hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
+    int64_t next_ticket = 0;
     // profiling
     bool profiling = false;
     std::map<std::string, KernelStat> stats;
@@ -470,6 +481,13 @@ void dan_destroy(dan_t* h) {
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->async_ready) {
+        for (auto& sl : h->slot) {
+            (void)hipHostFree(sl.pin_in); (void)hipHostFree(sl.pin_out);
+            (void)hipEventDestroy(sl.ev_h2d); (void)hipEventDestroy(sl.ev_comp); (void)hipEventDestroy(sl.ev_done);
+        }
+        (void)hipStreamDestroy(h->s_h2d); (void)hipStreamDestroy(h->s_comp); (void)hipStreamDestroy(h->s_d2h);
+    }
     for (auto& kv : h->stats) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : h->event_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete h;
@@ -578,6 +596,8 @@ int dan_forward_aux(dan_t* h, const uint8_t* reads, const uint8_t* qual, const u
     if (n_sites < 0) return fail(h, DAN_ERR_INVALID_ARG, "negative site count");
     if (n_sites == 0) return DAN_OK;
     if (!reads || !qual || !strand || !ref || !ref_mask || !var_mask) return fail(h, DAN_ERR_INVALID_ARG, "null input plane");
+    if (h->slot[0].ticket >= 0 || h->slot[1].ticket >= 0)      // (the workspaces are shared and the streams differ)
+        return fail(h, DAN_ERR_STATE, "dan_forward while asynchronous batches are in flight: dan_wait for them first");
     const dan_config& c = h->cfg;
     HIPCHK(h, hipSetDevice(c.device_id));
     const size_t rl = (size_t)c.reads * c.length, L = c.length;
@@ -608,6 +628,87 @@ int dan_forward(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8
                 const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits, float* vt_logits,
                 float* vt_prob, float* bp) {
     return dan_forward_aux(h, reads, qual, strand, ref, ref_mask, var_mask, n_sites, bin_logits, vt_logits, vt_prob, bp, nullptr);
+}
+
+static const int OUT_W[5] = {2, 3, 3, 1, 22};            // floats per site of bin_logits, vt_logits, vt_prob, bp, aux
+
+static int async_init(dan_handle* h) {
+    const dan_config& c = h->cfg;
+    const size_t in_site = (size_t)3 * c.reads * c.length + 3 * c.length;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+    for (auto& sl : h->slot) {
+        HIPCHK(h, hipHostMalloc((void**)&sl.pin_in, (size_t)h->max_batch * in_site, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&sl.pin_out, (size_t)h->max_batch * 31 * sizeof(float), hipHostMallocDefault));
+        int rc = dev_alloc(h, &sl.dev_in, (size_t)h->max_batch * in_site); if (rc) return rc;
+        rc = dev_alloc(h, &sl.dev_out, (size_t)h->max_batch * 31); if (rc) return rc;
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    }
+    h->async_ready = true;
+    return DAN_OK;
+}
+
+int dan_forward_async(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
+                      const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
+                      float* vt_logits, float* vt_prob, float* bp, float* aux, int64_t* ticket) {
+    if (!h || !ticket) return DAN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DAN_ERR_STATE, "dan_forward_async before dan_finalize");
+    if (n_sites < 0 || n_sites > h->max_batch)
+        return fail(h, DAN_ERR_INVALID_ARG, "dan_forward_async takes 0..max_batch (%d) sites per call, got %lld", h->max_batch, (long long)n_sites);
+    if (n_sites > 0 && (!reads || !qual || !strand || !ref || !ref_mask || !var_mask)) return fail(h, DAN_ERR_INVALID_ARG, "null input plane");
+    const dan_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device_id));
+    if (!h->async_ready) { int rc = async_init(h); if (rc) return rc; }
+    dan_handle::Slot& sl = h->slot[h->next_ticket & 1];
+    if (sl.ticket >= 0)
+        return fail(h, DAN_ERR_STATE, "two batches are already in flight: dan_wait(%lld) first", (long long)sl.ticket);
+    const size_t nb = (size_t)n_sites, rl = (size_t)c.reads * c.length, L = c.length;
+    const size_t in_bytes = nb * (3 * rl + 3 * L);
+    uint8_t* p = sl.pin_in;
+    const uint8_t* src[6] = {reads, qual, strand, ref, ref_mask, var_mask};
+    size_t off[7] = {0, nb * rl, 2 * nb * rl, 3 * nb * rl, 3 * nb * rl + nb * L, 3 * nb * rl + 2 * nb * L, in_bytes};
+    for (int i = 0; i < 6 && nb; ++i) memcpy(p + off[i], src[i], off[i + 1] - off[i]);
+    if (nb) {
+        HIPCHK(h, hipMemcpyAsync(sl.dev_in, sl.pin_in, in_bytes, hipMemcpyHostToDevice, h->s_h2d));
+        HIPCHK(h, hipEventRecord(sl.ev_h2d, h->s_h2d));
+        HIPCHK(h, hipStreamWaitEvent(h->s_comp, sl.ev_h2d, 0));
+        uint8_t* d = sl.dev_in;
+        float *o_bin = sl.dev_out, *o_vt = o_bin + nb * 2, *o_p = o_vt + nb * 3, *o_bp = o_p + nb * 3, *o_aux = o_bp + nb;
+        int rc = dan_forward_device(h, d + off[0], d + off[1], d + off[2], d + off[3], d + off[4], d + off[5], n_sites, o_bin, o_vt,
+                                    o_p, o_bp, o_aux, (void*)h->s_comp);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(sl.ev_comp, h->s_comp));
+        HIPCHK(h, hipStreamWaitEvent(h->s_d2h, sl.ev_comp, 0));
+        HIPCHK(h, hipMemcpyAsync(sl.pin_out, sl.dev_out, nb * 31 * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+        HIPCHK(h, hipEventRecord(sl.ev_done, h->s_d2h));
+    }
+    sl.ticket = h->next_ticket++;
+    sl.n = n_sites;
+    sl.dst[0] = bin_logits; sl.dst[1] = vt_logits; sl.dst[2] = vt_prob; sl.dst[3] = bp; sl.dst[4] = aux;
+    *ticket = sl.ticket;
+    return DAN_OK;
+}
+
+int dan_wait(dan_t* h, int64_t ticket) {
+    if (!h) return DAN_ERR_INVALID_ARG;
+    if (!h->async_ready || ticket < 0) return fail(h, DAN_ERR_STATE, "dan_wait(%lld): no such batch in flight", (long long)ticket);
+    dan_handle::Slot& sl = h->slot[ticket & 1];
+    if (sl.ticket != ticket) return fail(h, DAN_ERR_STATE, "dan_wait(%lld): no such batch in flight", (long long)ticket);
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t nb = (size_t)sl.n;
+    if (nb) {
+        HIPCHK(h, hipEventSynchronize(sl.ev_done));
+        const float* src = sl.pin_out;
+        for (int i = 0; i < 5; ++i) {
+            if (sl.dst[i]) memcpy(sl.dst[i], src, nb * OUT_W[i] * sizeof(float));
+            src += nb * OUT_W[i];
+        }
+    }
+    sl.ticket = -1;
+    return DAN_OK;
 }
 
 int dan_set_tap(dan_t* h, int32_t layer) {

@@ -964,55 +964,96 @@ void launch_highway(const float* h, long long hls, const float* wc, long long wc
 }
 
 // ------------------------------------------------------------------------------------------------
-// FC:  C[M][N] = act(A[M][K] * W[N][K]^T + bias)   -- both operands K-contiguous (torch Linear layout)
-// workgroup tile 64 x 64 (2 x 2 waves of 32 x 32), fragments straight from L2/HBM
+// FC:  C[M][N] = act(A[M][K] * W[N][K]^T + bias)   -- both operands K-contiguous (torch Linear layout), model.py:362-377,917
+// Workgroup tile 128 x 128, k-tiles of 32 staged through LDS in full 128-byte lines (8 lanes x 16 B per row; fragment-shaped
+// loads straight from L2 -- 16 rows x 64 B per instruction -- made the 64 x 64 kernel of round 1 load-path bound at 67 TF),
+// double-buffered: the next k-tile's global loads are issued before the MFMAs of the current one and written to the other
+// LDS buffer after them, one barrier per k-tile.  8 waves = 2 (m) x 4 (n), each 64 x 32 (8 accumulator tiles); fragments
+// are ds_read_b128 with the k order inside a 16-group permuted as everywhere else (one 16-byte read feeds four k-steps);
+// row stride 40 dwords: the four 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) then touch rows of all 8
+// residues mod 8 at two k offsets -- conflict-free.  XCD-aware tile order: workgroups b and b + 8 share an XCD, so tiles are
+// dealt in contiguous runs per XCD (n fastest): an XCD's 32 tiles share 4 row blocks of A and all of W's 8 column blocks,
+// A streams from HBM once and W once per XCD.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ A, long long lda,
-                                                 const float* __restrict__ W, long long ldw,
-                                                 const float* __restrict__ bias, float* __restrict__ C, long long ldc,
-                                                 int M, int N, int K, int relu) {
+constexpr int FC_BM = 128, FC_BN = 128, FC_BK = 32, FC_S = FC_BK + 8, FC_THREADS = 512;
+__global__ __launch_bounds__(FC_THREADS) void fc_kernel(const float* __restrict__ A, long long lda,
+                                                        const float* __restrict__ W, long long ldw,
+                                                        const float* __restrict__ bias, float* __restrict__ C, long long ldc,
+                                                        int M, int N, int K, int relu, int tiles_n, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float sa[2][FC_BM * FC_S], sw[2][FC_BN * FC_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
-    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
-    const float *ap[2], *wp[2];
+    // tile of this workgroup (XCD-contiguous order)
+    const int per = (n_tiles + 7) >> 3;
+    const int q = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || q >= n_tiles) return;
+    const int bm = (q / tiles_n) * FC_BM, bn = (q % tiles_n) * FC_BN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+    // staging: thread -> rows (tid >> 3) + 64 i, 16-byte column tid & 7
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+    const float *ga[2], *gw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        ap[i] = A + (size_t)min(m0 + i * 16 + r16, M - 1) * lda + kk * 4;
-        wp[i] = W + (size_t)min(n0 + i * 16 + r16, N - 1) * ldw + kk * 4;
+        ga[i] = A + (size_t)min(bm + srow + 64 * i, M - 1) * lda + sc4;
+        gw[i] = W + (size_t)min(bn + srow + 64 * i, N - 1) * ldw + sc4;
     }
-    v4f acc[2][2];
+    v4f ra[2], rw[2];
+    auto gload = [&](int k0) {
+        const bool in = k0 + sc4 < K;                           // K is a multiple of 4 (16, in fact): whole vectors
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = in ? *(const v4f*)(ga[i] + k0) : splat(0.f);
+            rw[i] = in ? *(const v4f*)(gw[i] + k0) : splat(0.f);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(v4f*)(&sa[buf][(srow + 64 * i) * FC_S + sc4]) = ra[i];
+            *(v4f*)(&sw[buf][(srow + 64 * i) * FC_S + sc4]) = rw[i];
+        }
+    };
+    v4f acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = splat(0.f);
-    const int G = K / 16;
-    v4f an[2], wn[2];
+    const int KT = (K + FC_BK - 1) / FC_BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) gload((kt + 1) * FC_BK);
+        const float* pa = &sa[cur][(wm + r16) * FC_S + kk * 4];
+        const float* pw = &sw[cur][(wn + r16) * FC_S + kk * 4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { an[i] = *(const v4f*)ap[i]; wn[i] = *(const v4f*)wp[i]; }
-    for (int g = 0; g < G; ++g) {
-        v4f a[2], w[2];
+        for (int g = 0; g < FC_BK / 16; ++g) {
+            v4f a[4], w[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { a[i] = an[i]; w[i] = wn[i]; }
-        const int gn = (g + 1 < G) ? g + 1 : g;
+            for (int i = 0; i < 4; ++i) a[i] = *(const v4f*)(pa + i * 16 * FC_S + g * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { an[i] = *(const v4f*)(ap[i] + (size_t)gn * 16); wn[i] = *(const v4f*)(wp[i] + (size_t)gn * 16); }
+            for (int j = 0; j < 2; ++j) w[j] = *(const v4f*)(pw + j * 16 * FC_S + g * 16);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i][s], w[j][s], acc[i][j]);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i][s], w[j][s], acc[i][j]);
+        }
+        if (kt + 1 < KT) sstore(cur ^ 1);
+        __syncthreads();
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n0 + j * 16 + r16;
+        const int n = bn + wn + j * 16 + r16;
         if (n >= N) continue;
         const float b = bias[n];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int m = m0 + i * 16 + kk * 4 + jj;
+                const int m = bm + wm + i * 16 + kk * 4 + jj;
                 if (m < M) {
                     float v = acc[i][j][jj] + b;
                     if (relu) v = fmaxf(v, 0.f);
@@ -1024,8 +1065,9 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ A, lo
 
 void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
                long long ldc, int M, int N, int K, int relu, hipStream_t s) {
-    hipLaunchKernelGGL(fc_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc, M, N,
-                       K, relu);
+    const int tiles_m = (M + FC_BM - 1) / FC_BM, tiles_n = (N + FC_BN - 1) / FC_BN, n_tiles = tiles_m * tiles_n;
+    const int grid = ((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(fc_kernel, dim3(grid), dim3(FC_THREADS), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K, relu, tiles_n, n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -19,6 +19,39 @@ from .shard import shard_range
 from .vcf import scored_record
 
 
+class _Pipeline:
+    """One batch of lookahead over ``net``: batch k+1 is enqueued (``forward_u8_async``: pinned staging, H2D on a copy
+    stream) before batch k's scores are awaited and formatted, so the VCF text formatting -- the reference formats each
+    score with ``'%.8f' % tensor``, one D2H sync per scalar, utils.py:168-178 -- and the loader hand-off overlap the
+    forward.  A model without the asynchronous pair (the CPU test double) is called synchronously."""
+
+    def __init__(self, net, write, use_var_type_threshold):
+        self.net, self.write, self.vt_thr = net, write, use_var_type_threshold
+        self.pending = None
+        self.async_ok = hasattr(net, "forward_u8_async")
+        self.max_batch = net.handle.query("max_batch") if self.async_ok else 0
+
+    def _emit(self, batch, out):
+        vt = out["vt_prob"]
+        bp = (1.0 - vt[:, 0]) if self.vt_thr else out["bp"]                   # trainer.py:611-621
+        self.write("".join(scored_record(r, b, v) + "\n" for r, b, v in zip(batch.vcfrec, bp, vt)))
+
+    def submit(self, batch):
+        if self.async_ok and len(batch.vcfrec) <= self.max_batch:
+            token = self.net.forward_u8_async(*batch.arrays())
+            self.drain()
+            self.pending = (batch, token)
+        else:
+            self.drain()
+            self._emit(batch, self.net.forward_u8(*batch.arrays()))
+
+    def drain(self):
+        if self.pending is not None:
+            batch, token = self.pending
+            self.pending = None
+            self._emit(batch, self.net.wait(token))
+
+
 def score_records(net, source: CandidateFile, write: Callable[[str], None], lo: int = 0, hi: Optional[int] = None,
                   sites_per_launch: int = 4096, reads_seed: int = 0, use_var_type_threshold: bool = False,
                   log=None) -> int:
@@ -28,18 +61,17 @@ def score_records(net, source: CandidateFile, write: Callable[[str], None], lo: 
     hi = len(source) if hi is None else min(hi, len(source))
     done = 0
     t0 = time.perf_counter()
+    pipe = _Pipeline(net, write, use_var_type_threshold)
     for b0 in range(lo, hi, sites_per_launch):
         recs = source.read(b0, min(b0 + sites_per_launch, hi))
         # the seed is tied to the ABSOLUTE record index, so shard boundaries never change a site's read subset
         batch = assemble_batch(recs, cfg.reads, seed=reads_seed + b0, use_q=cfg.use_q, use_strand=cfg.use_strand)
-        out = net.forward_u8(*batch.arrays())
-        vt = out["vt_prob"]
-        bp = (1.0 - vt[:, 0]) if use_var_type_threshold else out["bp"]      # trainer.py:611-621
-        write("".join(scored_record(r, b, v) + "\n" for r, b, v in zip(batch.vcfrec, bp, vt)))
+        pipe.submit(batch)
         done += len(recs)
         if log:
             dt = time.perf_counter() - t0
-            log("  scored %d/%d sites (%.0f sites/s)" % (done, hi - lo, done / max(dt, 1e-9)))
+            log("  submitted %d/%d sites (%.0f sites/s)" % (done, hi - lo, done / max(dt, 1e-9)))
+    pipe.drain()
     return done
 
 
@@ -56,19 +88,18 @@ def score_file_native(net, hdf_path: str, write: Callable[[str], None], lo: int,
     t0 = time.perf_counter()
     with NativeLoader(hdf_path, cfg.reads, batch_sites=sites_per_launch, lo=lo, hi=hi, seed=reads_seed,
                       threads=threads) as nl:
+        pipe = _Pipeline(net, write, use_var_type_threshold)
         for batch in nl:
             if not cfg.use_q:
                 batch.qual[:] = 0
             if not cfg.use_strand:
                 batch.strand[:] = 0
-            out = net.forward_u8(*batch.arrays())
-            vt = out["vt_prob"]
-            bp = (1.0 - vt[:, 0]) if use_var_type_threshold else out["bp"]
-            write("".join(scored_record(r, b, v) + "\n" for r, b, v in zip(batch.vcfrec, bp, vt)))
+            pipe.submit(batch)
             done += len(batch)
             if log:
                 dt = time.perf_counter() - t0
-                log("  scored %d/%d sites (%.0f sites/s)" % (done, hi - lo, done / max(dt, 1e-9)))
+                log("  submitted %d/%d sites (%.0f sites/s)" % (done, hi - lo, done / max(dt, 1e-9)))
+        pipe.drain()
     return done
 
 

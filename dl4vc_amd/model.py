@@ -87,6 +87,16 @@ class DanNet:
             raise RuntimeError("load_state_dict() first")
         return self.handle.forward(reads, qual, strand, ref, ref_mask, var_mask, aux=aux)
 
+    def forward_u8_async(self, reads, qual, strand, ref, ref_mask, var_mask, aux: bool = False):
+        """Enqueue a batch (<= max_batch sites); returns a token for ``wait``.  Two batches may be in flight: H2D of batch
+        k+1 and the caller's post-processing of batch k-1 overlap the forward of batch k (include/dl4vc_dan.h)."""
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        return self.handle.forward_async(reads, qual, strand, ref, ref_mask, var_mask, aux=aux)
+
+    def wait(self, token) -> Dict[str, np.ndarray]:
+        return self.handle.wait(token)
+
     # ---- reference-compatible call (trainer.py:569-572) -------------------------------------------
     def __call__(self, reads, ref, q_scores=None, strands=None, binary_trust_vector=None, af_scores=None,
                  ref_bases=None, var_bases=None, ref_masks=None, var_masks=None,

@@ -20,8 +20,9 @@
 extern "C" {
 #endif
 
-/* ABI history: 1 = first release; 2 = dan_config.conv_algo; 3 = dan_config.skip_empty_rows (struct grows at the end). */
-#define DAN_ABI_VERSION 3
+/* ABI history: 1 = first release; 2 = dan_config.conv_algo; 3 = dan_config.skip_empty_rows (struct grows at the end);
+ * 4 = dan_forward_async / dan_wait. */
+#define DAN_ABI_VERSION 4
 #define DAN_MAX_LAYERS 16
 
 typedef enum dan_status {
@@ -104,6 +105,20 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                        const uint8_t* ref, const uint8_t* ref_mask, const uint8_t* var_mask,
                        int64_t n_sites, float* bin_logits, float* vt_logits, float* vt_prob, float* bp,
                        float* aux, void* stream);
+
+/* Asynchronous forward on HOST buffers, double-buffered (SURVEY.md section 8b "Ownership": the reference's loop
+ * overlaps nothing -- DataLoader hand-off, H2D scatter, forward, .cpu() and the per-scalar '%.8f' formatting run back to
+ * back, trainer.py:518-572,629-630, utils.py:168-178).  dan_forward_async() copies the six input planes into one of TWO
+ * pinned staging slots (the caller's input buffers are free again when it returns), enqueues H2D on a copy stream, the
+ * forward on the compute stream and the D2H of the scores into the slot's pinned output block on a second copy stream,
+ * and returns a ticket.  dan_wait(ticket) blocks until that batch's scores have arrived and copies them to the output
+ * pointers given at enqueue (caller-owned, must stay valid until then; any may be NULL).  At most two tickets can be
+ * in flight: a third dan_forward_async before the oldest was waited for fails with DAN_ERR_STATE.  n_sites <= max_batch.
+ * Results are bit-identical to dan_forward.  Typical loop: enqueue batch k+1, wait for k, format k's VCF records. */
+int dan_forward_async(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand,
+                      const uint8_t* ref, const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites,
+                      float* bin_logits, float* vt_logits, float* vt_prob, float* bp, float* aux, int64_t* ticket);
+int dan_wait(dan_t* h, int64_t ticket);
 
 /* Parity-test taps (debug export).  dan_set_tap(): keep a copy of the activations after conv layer
  * `layer` (1..layers; 0 = the encoded 48-channel input; -1 = off) of the LAST chunk processed.

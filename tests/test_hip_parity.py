@@ -166,6 +166,44 @@ def test_chunk_and_batch_boundaries_do_not_change_results():
     a.close(); b.close()
 
 
+def test_async_forward_pair_is_bit_identical_and_ordered():
+    """dan_forward_async / dan_wait (SURVEY.md section 8b "Ownership"): two batches in flight, results bit-identical to
+    the synchronous call, inputs free again at return, call-order errors are loud."""
+    cfg = DanConfig(reads=12, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))
+    sd = random_state_dict(cfg, seed=5)
+    net = DanNet(cfg, max_batch=16, chunk_sites=8).load_state_dict(sd)
+    batches = [synth.make_sites(n, reads=12, seed=60 + i) for i, n in enumerate((16, 7, 16, 1))]
+    want = [net.forward_u8(*b.arrays(), aux=True) for b in batches]
+    got, prev = [], None
+    for b in batches:
+        arrs = [a.copy() for a in b.arrays()]
+        tok = net.forward_u8_async(*arrs, aux=True)
+        for a in arrs:
+            a[...] = 255                                         # the inputs were staged: clobbering them changes nothing
+        if prev is not None:
+            got.append(net.wait(prev))
+        prev = tok
+    got.append(net.wait(prev))
+    for g, w in zip(got, want):
+        for k in w:
+            np.testing.assert_array_equal(g[k], w[k], err_msg=k)
+    t0 = net.forward_u8_async(*batches[0].arrays())
+    t1 = net.forward_u8_async(*batches[1].arrays())
+    with pytest.raises(RuntimeError, match="in flight"):
+        net.forward_u8_async(*batches[2].arrays())
+    with pytest.raises(RuntimeError, match="in flight"):
+        net.forward_u8(*batches[2].arrays())
+    net.wait(t0)
+    with pytest.raises(RuntimeError, match="no such batch"):
+        net.wait(t0)
+    net.wait(t1)
+    with pytest.raises(RuntimeError, match="max_batch"):
+        net.forward_u8_async(*synth.make_sites(17, reads=12, seed=1).arrays())
+    e = net.wait(net.forward_u8_async(*[a[:0] for a in batches[0].arrays()]))
+    assert e["vt_prob"].shape == (0, 3)
+    net.close()
+
+
 def test_shape_errors_are_loud():
     cfg = DanConfig(reads=8, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))
     sd = random_state_dict(cfg, seed=5)
