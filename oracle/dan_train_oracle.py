@@ -264,3 +264,21 @@ def train_step_oracle(state_dict, cfg, planes, targets, hp: TrainHyper = TrainHy
         res["new:" + p + "running_mean"] = ((1 - BN_MOMENTUM) * sd[p + "running_mean"] + BN_MOMENTUM * mu).numpy()
         res["new:" + p + "running_var"] = ((1 - BN_MOMENTUM) * sd[p + "running_var"] + BN_MOMENTUM * var * (n / (n - 1.0))).numpy()
     return res
+
+
+def state_errors(new, ref_new, ref_grad, lr):
+    """How far an Adam-updated tensor is from the reference's, split by how well-conditioned the update is.
+
+    Adam's first steps move every element by ~lr * g / (|g| + eps): where |g| is at the level of fp32 summation noise
+    (or of eps = 1e-8) the SIGN of g, and with it the whole +-lr step, depends on the summation order -- two correct
+    implementations legitimately differ by up to 2 * lr there.  Returns (worst |delta| / max|ref_new| over the elements whose
+    reference gradient is significant (|g| >= 1e-3 * max|g|), worst |delta| / lr over the other elements)."""
+    new, ref_new = np.asarray(new, np.float64), np.asarray(ref_new, np.float64)
+    d = np.abs(new - ref_new)
+    if ref_grad is None:
+        return float(d.max(initial=0.0)) / max(1e-12, float(np.abs(ref_new).max(initial=0.0))), 0.0
+    g = np.abs(np.asarray(ref_grad, np.float64))
+    sig = g >= 1e-3 * g.max(initial=0.0)
+    a = float(d[sig].max(initial=0.0)) / max(1e-12, float(np.abs(ref_new).max(initial=0.0)))
+    b = float(d[~sig].max(initial=0.0)) / lr
+    return a, b

@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Training fixtures under tests/golden/train_*.npz, produced by RUNNING THE REFERENCE'S OWN TRAINING LOOP.
+
+Build container only (needs /root/reference).  For each case the reference's ``dl4vc/trainer.py::train`` is called,
+unmodified, on ONE OR TWO batches that its own ``ContextDatasetFromNumpy`` + ``DataLoader`` collate from a record array
+in the HDF5 schema, with the argument namespace its own ``arguments.create_arg_parser()`` builds from the flag line of
+``train_variant_caller.sh:101-151``, ``optim.Adam(model.parameters(), lr=args.lr)`` as in ``main.py:116``.  Recorded:
+
+  * the batch the loop saw (six uint8 planes in OUR [B][R][L] order + the training targets) -- pins the training slice of
+    the dataset assembly (dataset.py:583-680);
+  * the dropout masks the three ``nn.Dropout`` drew (recovered by a global forward-pre-hook: RNG state saved, the mask
+    drawn on a tensor of ones, RNG state restored, so the reference's own draw is unchanged);
+  * the model outputs, the two focal criteria's outputs (global forward hook), the total loss (value of the tensor
+    ``backward()`` was called on), every parameter's gradient BEFORE clipping and the total norm (recorded by a wrapper
+    around ``torch.nn.utils.clip_grad_norm_`` that clones ``.grad`` and calls the original);
+  * the state dict after ``optimizer.step()`` (parameters + BN running statistics), the Adam moments, and the
+    close-example flags the loop wrote back into the dataset (trainer.py:263-264).
+
+Same shims as oracle/gen_golden.py (stub h5py/pysam, ``Tensor.cuda`` = identity, ``np.string_``) plus
+``torch.cuda.synchronize`` = no-op (trainer.py:442 calls it on the logging path).
+
+Usage:  python oracle/gen_golden_train.py
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.gen_golden import import_reference, build_reference_model, GOLD, REF      # noqa: E402
+from oracle.dan_oracle import OracleSpec, random_state_dict                            # noqa: E402
+from oracle.dan_train_oracle import TrainHyper, train_step_oracle, example_weights, trainable, state_errors   # noqa: E402
+from dl4vc_amd import synth                                                            # noqa: E402
+from dl4vc_amd.hdf5_schema import record_dtype                                         # noqa: E402
+
+# the flag line of train_variant_caller.sh:101-151 (file arguments replaced)
+TRAIN_FLAGS = ("--lr 0.0002 --grad-clip 1.0 --epochs 1 --log-interval 1 --gpus 1 --label-smoothing 0.001 --batch-size 80 "
+               "--test-batch-size 200 --model-hidden-dropout 0.1 --model-batchnorm --num-data-workers 0 --trust-snp-only "
+               "--non-snp-train-weight 2.0 --fp-train-weight 0.2 --model-use-q-scores --model-use-strands "
+               "--auxillary-loss-weight 1.0 --auxillary-loss-bases-weight 0.01 --auxillary-loss-allele-weight 0.001 "
+               "--loss-debug-freq 10000 --save_vcf_records --aux-keep-candidate-af --model-use-reads-ref-var-mask "
+               "--close_match_window 2.0 --focal_loss_alpha 1. --focal_loss_gamma 0.2 --model-conv-layers 7 "
+               "--model-residual-layer-start 5 --model-ave-pool-layers 2 --early_loss_weight 0.1 "
+               "--model-init-conv-channels 128 --rm_var_reads_rate 0.0 --rm_non_var_reads_rate 0.0 "
+               "--close_examples_sample_rate 0.15 --delay_augmentation_epochs 1 --save_hard_example_records "
+               "--learn_early_loss_weight --model_pool_combine_dimension 0 --model-final-conv-channels 128 "
+               "--model-bottleneck-size 32 --model_final_layer_dilation 2 --model_middle_layer_dilation 2 "
+               "--model_concat_hw_reads --model-highway-single-reads").split()
+
+GT_COLUMN = ("GT:0/1", "GT:1/1", "GT:0/0", "GT:1|0", "GT:0/1", "GT:1/1", "GT:./.", "GT:0|1")
+LABELS = (0, 0, 2, 1, 0, 1, 2, 0)          # {0: TP, 1: FN, 2: FP}  trainer.py:133
+
+
+def make_records(n_sites: int, reads: int, seed: int):
+    """Candidate records in the converter's schema with a truth column (vcfrec column 11, utils.py:59-70)."""
+    sites = synth.make_sites(n_sites, reads=reads, seed=seed)
+    recs = np.zeros(n_sites, dtype=record_dtype(200, 201))
+    for i in range(n_sites):
+        recs[i]["name"] = ("chr20:%d" % (1000 + 7 * i)).encode()
+        recs[i]["single_reads"][:reads] = sites.reads[i]
+        recs[i]["q-scores"][:reads] = sites.qual[i]
+        recs[i]["strand"][:reads] = sites.strand[i]
+        recs[i]["ref_bases"] = sites.ref[i]
+        recs[i]["num_reads"] = int(sites.num_reads[i])
+        recs[i]["label"] = LABELS[i % len(LABELS)]
+        rec = sites.vcfrec[i] + "\t" + GT_COLUMN[i % len(GT_COLUMN)]
+        assert len(rec) < 128
+        recs[i]["vcfrec"] = rec.encode()
+    return recs
+
+
+def reference_args(save_dir: str, **over):
+    import importlib
+    mod = importlib.import_module("arguments")
+    assert mod.__file__.startswith(REF), mod.__file__
+    args = mod.create_arg_parser().parse_args(TRAIN_FLAGS + ["--save_vcf_records_file", os.path.join(save_dir, "model_test.vcf"),
+                                              "--test_file", os.path.join(save_dir, "test.hdf"), "--train_file", os.path.join(save_dir, "train.hdf")])
+    for k, v in over.items():
+        assert hasattr(args, k), k
+        setattr(args, k, v)
+    return args
+
+
+def hyper_from_args(args) -> TrainHyper:
+    return TrainHyper(lr=args.lr, grad_clip=args.grad_clip, label_smoothing=args.label_smoothing,
+                      close_match_window=args.close_match_window, focal_alpha=args.focal_loss_alpha,
+                      focal_gamma=args.focal_loss_gamma, fp_train_weight=args.fp_train_weight,
+                      non_snp_train_weight=args.non_snp_train_weight, binary_weight=args.binary_weight,
+                      aux_weight=args.auxillary_loss_weight, aux_bases_weight=args.auxillary_loss_bases_weight,
+                      aux_allele_weight=args.auxillary_loss_allele_weight, dropout=args.model_hidden_dropout)
+
+
+class Recorder:
+    """Global module hooks + two wrappers on torch functions (never on reference code)."""
+
+    def __init__(self):
+        self.steps = []
+        self.cur = None
+        self.handles = []
+
+    def start(self):
+        import torch.nn.modules.module as M
+        self.handles.append(M.register_module_forward_pre_hook(self._pre))
+        self.handles.append(M.register_module_forward_hook(self._post))
+        self._orig_backward = torch.Tensor.backward
+        self._orig_clip = torch.nn.utils.clip_grad_norm_
+        rec = self
+
+        def backward(t, *a, **k):
+            rec.cur["loss"] = np.asarray(t.detach().numpy())
+            return rec._orig_backward(t, *a, **k)
+
+        def clip(parameters, max_norm, *a, **k):
+            params = list(parameters)
+            rec.cur["grads"] = [None if p.grad is None else p.grad.detach().clone().numpy() for p in params]
+            norm = rec._orig_clip(params, max_norm, *a, **k)
+            rec.cur["grad_norm"] = np.asarray(float(norm))
+            return norm
+
+        torch.Tensor.backward = backward
+        torch.nn.utils.clip_grad_norm_ = clip
+
+    def stop(self):
+        for h in self.handles:
+            h.remove()
+        torch.Tensor.backward = self._orig_backward
+        torch.nn.utils.clip_grad_norm_ = self._orig_clip
+
+    def _pre(self, mod, inp):
+        name = type(mod).__name__
+        if name == "Basic2DNet":
+            self.cur = {"masks": [], "criteria": []}
+            self.steps.append(self.cur)
+        elif name == "Dropout" and mod.training and self.cur is not None:
+            state = torch.get_rng_state()
+            ones = torch.ones_like(inp[0])
+            m = torch.nn.functional.dropout(ones, mod.p, True)
+            torch.set_rng_state(state)
+            self.cur["masks"].append((m != 0).numpy().astype(np.uint8))
+
+    def _post(self, mod, inp, out):
+        name = type(mod).__name__
+        if name == "Basic2DNet":
+            self.cur["outputs"] = [o.detach().numpy().copy() for o in out[:6]]
+        elif name == "SoftBCEWithLogitsFocalLoss":
+            self.cur["criteria"].append((np.asarray(out[0].detach().numpy()), out[1].numpy().copy()))
+
+
+def run_case(name: str, spec: OracleSpec, n_sites: int, n_steps: int, seed: int, mods, dropout=0.1, **arg_over):
+    m, d, u = mods
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer = importlib.import_module("dl4vc.trainer")
+    torch.cuda.synchronize = lambda *a, **k: None
+    from torch.utils.data import DataLoader
+    td = tempfile.mkdtemp()
+    args = reference_args(td, model_hidden_dropout=dropout, model_batchnorm=spec.use_bn, **arg_over)
+    recs = make_records(n_sites * n_steps, spec.reads, seed)
+    npy = os.path.join(td, "train.npy")
+    np.save(npy, recs)
+    sd0 = random_state_dict(spec, seed=seed + 1, dropout_keys=dropout > 0)
+    # the heads of the seeded network are scaled so that its logits are O(1): saturated softmaxes would make the focal
+    # weights and the close-example flags trivial
+    for k in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
+        sd0[k + ".weight"] = (sd0[k + ".weight"] * np.float32(0.15)).astype(np.float32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = build_reference_model(m, spec, dropout)
+        sd_t = {k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd0.items()}
+        for k, v in net.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                sd_t[k] = v
+        net.load_state_dict(sd_t, strict=True)
+        opt = torch.optim.Adam(net.parameters(), lr=args.lr)                               # main.py:116
+        # max_reads is a constructor argument of the reference's dataset (default MAX_READS = 100, dataset.py:398,410)
+        ds = d.ContextDatasetFromNumpy(npy, args=args, max_reads=spec.reads, holdout_chromosomes=[],
+                                       augment_single_reads=False, augment_refernce=False)
+        loader = DataLoader(ds, batch_size=n_sites, shuffle=False)
+        batches = list(loader)                    # what the loop will see (the loop re-iterates the loader itself)
+        rec = Recorder()
+        torch.manual_seed(seed)
+        rec.start()
+        try:
+            trainer.train(args, net, torch.device("cpu"), loader, opt, 1, train_dataset=ds, debug=False)
+        finally:
+            rec.stop()
+    assert len(rec.steps) == n_steps, len(rec.steps)
+    names = [k for k, _ in net.named_parameters()]
+    hp = hyper_from_args(args)
+    payload = {"spec_json": np.frombuffer(json.dumps(spec.__dict__, default=list).encode(), np.uint8),
+               "hyper_json": np.frombuffer(json.dumps(hp.__dict__).encode(), np.uint8),
+               "n_steps": np.asarray(n_steps)}
+    for k, v in sd0.items():
+        payload["w:" + k] = v
+    state = {k: v for k, v in sd0.items()}
+    adam = None
+    worst = {}
+    for s, (st, items) in enumerate(zip(rec.steps, batches)):
+        tag = "s%d:" % s
+        planes = [np.ascontiguousarray(np.transpose(items[k].numpy().astype(np.uint8), (0, 2, 1)))
+                  for k in ("reads", "q-scores", "strands")]
+        planes += [items[k].numpy().astype(np.uint8) for k in ("ref", "ref_mask", "var_mask")]
+        for k, v in zip(("reads", "qual", "strand", "ref", "ref_mask", "var_mask"), planes):
+            payload[tag + "in:" + k] = v
+        tg = {"label": items["label"].numpy().astype(np.int64).reshape(-1), "var_type": items["var_type"].numpy().astype(np.int64),
+              "allele_freq": items["allele_freq"].numpy().astype(np.float32), "coverage": items["coverage"].numpy().astype(np.float32),
+              "var_base_enum": items["var_base_enum"].numpy().astype(np.int64), "var_ref_enum": items["var_ref_enum"].numpy().astype(np.int64),
+              "is_snp": items["is_snp"].numpy().astype(np.uint8)}
+        tg["weight"] = example_weights(tg["is_snp"], hp)
+        for k, v in tg.items():
+            payload[tag + "tg:" + k] = v
+        payload[tag + "vcfrec"] = np.frombuffer("\n".join(items["vcfrec"]).encode(), np.uint8)
+        for i, mk in enumerate(st["masks"]):
+            payload[tag + "mask%d" % i] = np.packbits(mk, axis=None)
+            payload[tag + "mask%d_shape" % i] = np.asarray(mk.shape)
+        for k, v in zip(("bin_logits", "vt_logits", "af", "cov", "vb", "vr"), st["outputs"]):
+            payload[tag + "out:" + k] = v
+        assert len(st["criteria"]) == 4           # the loop evaluates both criteria twice (trainer.py:221-224, :252-255)
+        payload[tag + "bin"] = st["criteria"][2][0]
+        payload[tag + "vt"] = st["criteria"][3][0]
+        payload[tag + "bin_close"] = st["criteria"][2][1]
+        payload[tag + "vt_close"] = st["criteria"][3][1]
+        payload[tag + "loss"] = st["loss"]
+        payload[tag + "grad_norm"] = st["grad_norm"]
+        for k, g in zip(names, st["grads"]):
+            if g is not None:
+                payload[tag + "grad:" + k] = g
+            else:
+                # no gradient reaches: the early-loss mixing scalars; the BatchNorm affine when --model-batchnorm is off
+                # (the reference builds the modules anyway, model.py:217, and never calls them)
+                assert not trainable(k) or (k.startswith("bn1D_layers") and not spec.use_bn), k
+        # ---- the oracle on the same step (checked here, so that a fixture never ships with an oracle that disagrees)
+        mine = train_step_oracle(state, spec, planes, tg, hp, dropout_masks=st["masks"], adam_state=adam, step=s + 1)
+        for k in ("loss", "bin", "vt"):
+            worst["loss"] = max(worst.get("loss", 0.0), abs(float(mine[k]) - float(payload[tag + k])))
+        for k, g in zip(names, st["grads"]):
+            if g is not None:
+                e = float(np.abs(mine["grad:" + k] - g).max()) / max(1e-12, float(np.abs(g).max()))
+                worst["grad"] = max(worst.get("grad", 0.0), e)
+        worst["norm"] = max(worst.get("norm", 0.0), abs(float(mine["grad_norm"]) - float(st["grad_norm"])) / float(st["grad_norm"]))
+        assert np.array_equal(mine["vt_close"], st["criteria"][3][1])
+        state = dict(state)
+        for k in list(mine):
+            if k.startswith("new:"):
+                state[k[4:]] = mine[k]
+        adam = {k: v for k, v in mine.items() if k.startswith(("m:", "v:"))}
+    # ---- final state of the REFERENCE after its optimizer steps
+    final = {k: v.detach().numpy().copy() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+    for k, v in final.items():
+        payload["final:" + k] = v
+        g = payload.get("s%d:grad:%s" % (n_steps - 1, k))
+        a, b = state_errors(state[k], v, g, hp.lr)
+        worst["state"] = max(worst.get("state", 0.0), a)
+        worst["state_noise_lr"] = max(worst.get("state_noise_lr", 0.0), b)
+    ost = opt.state_dict()["state"]
+    for i, k in enumerate(names):
+        if i in ost:
+            payload["adam_m:" + k] = ost[i]["exp_avg"].numpy().copy()
+            payload["adam_v:" + k] = ost[i]["exp_avg_sq"].numpy().copy()
+    payload["close_examples"] = ds.close_examples.copy()
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **payload)
+    print("wrote %-22s %7.1f KB   oracle vs reference: %s" % (os.path.basename(path), os.path.getsize(path) / 1024,
+                                                             {k: "%.2g" % v for k, v in worst.items()}))
+    assert worst["loss"] < 1e-5 and worst["grad"] < 1e-4 and worst["state"] < 1e-4 and worst["state_noise_lr"] < 2.1 * n_steps, worst
+    return worst
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    mods = import_reference()
+    small = OracleSpec(reads=8, length=201, layers=7, c_init=16, c_final=16, bottleneck=4, fc_sizes=(6, 8))
+    run_case("train_small", small, n_sites=6, n_steps=2, seed=300, mods=mods)
+    tiny = dict(reads=4, length=201, c_init=8, c_final=8, bottleneck=2, fc_sizes=(4, 4))
+    variants = {
+        "nobn": (OracleSpec(**tiny, use_bn=False), 0.0),                      # no BatchNorm, no dropout (conv2hidden.0/.3 keys)
+        "pool24": (OracleSpec(**tiny, pool_layers=(2, 4)), 0.1),
+        "l5res2": (OracleSpec(**tiny, layers=5, residual_start=2, pool_layers=(1,), dil_mid=3, dil_final=1), 0.1),
+        "nohw": (OracleSpec(**{**tiny, "bottleneck": 0}), 0.1),
+        "cfinal": (OracleSpec(**{**tiny, "c_final": 16}, residual_start=3), 0.1),
+    }
+    for i, (name, (spec, p)) in enumerate(variants.items()):
+        run_case("train_var_" + name, spec, n_sites=4, n_steps=1, seed=400 + 10 * i, mods=mods, dropout=p)
+
+
+if __name__ == "__main__":
+    main()
