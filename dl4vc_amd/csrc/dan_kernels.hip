@@ -15,17 +15,9 @@
 // Reference semantics followed (file:line in /root/reference): dl4vc/model.py:450-627 (encode),
 // :728-778 (layer loop), :824-859 (pool + highway concat), :917-958 (FC + heads),
 // dl4vc/trainer.py:609-623 (softmax scores).
-#include "dan_kernels.h"
+#include "dan_device.h"
 
 namespace dan {
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
 
 // Diagnostic build only (tools/seg_probe.hip defines DAN_STAMPS): per-wave s_memtime stamps of the segment
 // kernel's phases.  In the shipped library the macro expands to nothing.
@@ -43,72 +35,6 @@ constexpr int NSTAMP = 64;
 #else
 #define STAMP(k) do {} while (0)
 #endif
-
-// ------------------------------------------------------------------------------------------------
-// implicit-GEMM core:  acc[m][n] (+)= sum_{tap,g,s} Wfrag[tap][g][n][s] * X[pos + shift(tap)][16g + 4kk + s]
-// ------------------------------------------------------------------------------------------------
-// Software pipeline: one continuous MFMA stream.  The B fragment of position tile m is single-buffered:
-// right after the eight MFMAs that consume it, the ds_read_b128 of the SAME tile for the next k-group is
-// issued, so it has twelve tiles of MFMAs (~3000 cycles) to land; the next k-group's weight fragments
-// (two 1-KiB global loads per wave) are issued at the top of the step.  sched_group_barrier pins the
-// {8 MFMA, 1 ds_read} interleave so that LDS issue never drains the matrix pipe.  The first k-group's
-// weight fragments are loaded by the caller well ahead of the call (a_first).
-typedef const __attribute__((address_space(1))) v4f* gv4f_ptr;     // global (not flat) loads
-
-// ReLU as ONE compiler-visible instruction (v_med3_f32 v, 0, +inf).  Not inline asm: an asm block that reads an
-// MFMA result is invisible to hipcc's hazard recognizer (no wait states are inserted between the MFMA and the asm),
-// and fmaxf costs two instructions (canonicalise + max).
-__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
-
-// One wave's share: acc[MTW][NT] = its 32 output channels x its position tiles [m_base, m_base + cnt), cnt = 7 or 6.
-__device__ __forceinline__ void gemm_tile(v4f (&acc)[NT], const v4f (&a)[NT], v4f& b, const float* next) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = mfma16(a[n][s], b[s], acc[n]);
-    b = *(const v4f*)next;
-}
-
-__device__ __forceinline__ void conv_gemm(v4f (&acc)[MTW][NT], const float* xs, gv4f_ptr wl, const v4f (&a_first)[NT],
-                                          int kg, int ntaps, int dil, int lane, int m_base, int cnt) {
-    const int pos = lane & 15, kk = lane >> 4;
-    const int total = ntaps * kg;
-    const int t0 = (ntaps == 3) ? -dil : 0;
-    const float* xrow = xs + (HALO + m_base * 16 + pos) * LDS_S + kk * 4;
-    const bool full = cnt == MTW;                              // wave-uniform
-    v4f a_nxt[NT], b[MTW];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) a_nxt[n] = a_first[n];
-    {
-        const float* xb = xrow + t0 * LDS_S;
-#pragma unroll
-        for (int m = 0; m < MTW - 1; ++m) b[m] = *(const v4f*)(xb + m * 16 * LDS_S);
-        b[MTW - 1] = full ? *(const v4f*)(xb + (MTW - 1) * 16 * LDS_S) : splat(0.f);
-    }
-    int t = 0, g = 0;
-    for (int it = 0; it < total; ++it) {
-        v4f a[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a[n] = a_nxt[n];
-        const int nx = (it + 1 < total) ? it + 1 : it;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a_nxt[n] = wl[(size_t)nx * (KGC * 64) + n * 64];
-        int tn = t, gn = g + 1;
-        if (gn == kg) { gn = 0; ++tn; }
-        if (it + 1 == total) { tn = t; gn = g; }             // last step: harmless re-read
-        const float* xn = xrow + (t0 + tn * dil) * LDS_S + gn * 16;
-#pragma unroll
-        for (int m = 0; m < MTW - 1; ++m) gemm_tile(acc[m], a, b[m], xn + m * 16 * LDS_S);
-        __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);         // the weight loads first
-#pragma unroll
-        for (int m = 0; m < MTW - 1; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);  // one tile's MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-        }
-        if (full) gemm_tile(acc[MTW - 1], a, b[MTW - 1], xn + (MTW - 1) * 16 * LDS_S);
-        t = tn; g = gn;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Winograd F(2,3) form of the dilation-2 convolutions (exact-fp32 MFMAs, 4 channel GEMMs per 2 outputs instead of 6):
@@ -209,69 +135,6 @@ __device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xro
 #pragma unroll
             for (int o = 0; o < 2; ++o) b[m][o] = *(const v4f*)(xrow + (4 * m + 2 * o) * LDS_S + gn * 16);
         }
-    }
-}
-
-// 128 -> 32 highway bottleneck (1x1 conv + ReLU) of the LDS-resident read, written to HBM.  Output unit
-// u = 2*pt + n (13 position tiles x 2 channel tiles) is owned by wave u % NWAVE: every wave has ONE channel tile
-// n = wave & 1 (so one weight fragment per k-group, no selects) and the position tiles pt = (wave >> 1) mod 4
-// -- 4/4/3/3/3/3/3/3 units, i.e. 7/7/6/6 per SIMD.  All eight weight fragments are preloaded by the caller (wf).
-// NW = participating waves: all 8 (standalone stage), or only the 4 OLDER waves (0..3, one per SIMD) when the GEMM is
-// deferred into the next layer's conv stage (see the Winograd layer body).
-template <int NW>
-__device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
-                                           int wave, int lane) {
-    constexpr int PSTEP = NW / 2;                         // position-tile stride of one wave
-    constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
-    // everything below is recomputed per call from an opaque copy of the lane index: hoisted out of the layer loop, the
-    // per-tile offsets and 64-bit store addresses would sit in registers through the conv GEMMs (and spill)
-    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // (not even the lane index is kept)
-    asm volatile("" : "+v"(lane));
-    const int pos = lane & 15, kk = lane >> 4;
-    const int n = wave & 1, p0 = wave >> 1;
-    const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
-    int roff[NBT];
-#pragma unroll
-    for (int i = 0; i < NBT; ++i) roff[i] = min(p0 + PSTEP * i, MT - 1) * 16 * LDS_S;
-    v4f acc[NBT], b[NBT];
-    {
-        const v4f bias = *(const v4f*)(bbot + n * 16 + kk * 4);
-#pragma unroll
-        for (int i = 0; i < NBT; ++i) acc[i] = bias;
-    }
-#pragma unroll
-    for (int i = 0; i < NBT; ++i) b[i] = *(const v4f*)(xrow + roff[i]);
-#pragma unroll
-    for (int g = 0; g < KGC; ++g) {
-        const int gn = (g + 1 < KGC) ? g + 1 : g;
-#pragma unroll
-        for (int i = 0; i < NBT; ++i) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[i] = mfma16(wf[g][s], b[i][s], acc[i]);
-            b[i] = *(const v4f*)(xrow + roff[i] + gn * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < NBT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NBT; ++i) {
-        const int pt = p0 + PSTEP * i, p = pt * 16 + pos;
-        if (pt < MT && p < L) {
-            v4f v = acc[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
-            *(v4f*)((char*)hrow + (unsigned)(p * HPAD + n * 16 + kk * 4) * 4u) = v;
-        }
-    }
-}
-
-__device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int tid) {
-    for (int i = tid; i < L * (CPAD / 4); i += SEG_THREADS) {
-        const int p = i >> 5, c4 = i & 31;
-        ((v4f*)dst)[i] = *(const v4f*)(xs + (HALO + p) * LDS_S + c4 * 4);
     }
 }
 

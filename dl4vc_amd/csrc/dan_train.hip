@@ -1,0 +1,1125 @@
+// HIP kernels of ONE TRAINING STEP of the DAN network for gfx950 (MI355X).  fp32, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// Reference semantics (file:line in /root/reference): train-mode forward dl4vc/model.py:434-961 under model.train()
+// (trainer.py:69): BatchNorm on batch statistics (model.py:749-751), dropout in conv2hidden (model.py:369-377); losses
+// trainer.py:82-96,134-172,221-224,309-313,425-427 and objectives.py:49-112; clip + Adam trainer.py:435-439, main.py:116;
+// embedding gradient rules model.py:143-145 (padding_idx, scale_grad_by_freq).
+//
+// Layout and schedule: see dan_train.h.  One workgroup (8 waves) = one read resident in LDS for ONE layer-shaped step
+// (train_row_kernel): the convolution, its transpose (data gradient), the 1x1 residual and bottleneck GEMMs and their
+// transposes are all the same implicit GEMM over the LDS image (conv_gemm of dan_device.h) with weights re-packed on the
+// device every step.  Weight gradients contract over positions (train_wgrad_kernel): persistent workgroups, both operands
+// staged per half read, split-K partials reduced in a fixed order.  Every reduction is deterministic (no atomics).
+#include "dan_device.h"
+#include "dan_train.h"
+
+namespace dan {
+
+// ------------------------------------------------------------------------------------------------
+// encode one read into an LDS image (dl4vc/model.py:450-627): canonical 48-channel order
+//   [read emb+pe (20) | ref emb+pe (20) | q*0.01 | strand*0.5 | refmatch | varmatch | lenmask | 0 0 0]
+// Every thread of the workgroup must call (barrier inside).  Rows [row_lo, row_hi) of the read are written to
+// img + (p - row_lo + row_off) * stride; the agree predicates are over the whole read.
+// ------------------------------------------------------------------------------------------------
+struct EncodeSrc {
+    const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
+    const float *emb, *pe;
+};
+__device__ __forceinline__ void encode_rows(float* img, int stride, int row_off, int row_lo, int row_hi, const EncodeSrc& e,
+                                            size_t read_idx, int site, int L, int tid) {
+    const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+    const int p = tid;
+    const bool in = p < L;
+    int tok = 0, q = 0, st = 0, rf = 0, rm = 0, vm = 0;
+    if (in) {
+        tok = e.reads[rbase + p]; q = e.qual[rbase + p]; st = e.strand[rbase + p];
+        rf = e.ref[sbase + p]; rm = e.ref_mask[sbase + p]; vm = e.var_mask[sbase + p];
+    }
+    const int agree_ref = __syncthreads_and((rm == 0) || (tok == rm));      // model.py:592-593
+    const int agree_var = __syncthreads_and((vm == 0) || (tok == vm));
+    if (in && p >= row_lo && p < row_hi) {
+        float* row = img + (size_t)(p - row_lo + row_off) * stride;
+        const float* er = e.emb + min(tok, VOCAB - 1) * EMBED;
+        const float* ef = e.emb + min(rf, VOCAB - 1) * EMBED;
+        const float* pp = e.pe + p * EMBED;
+#pragma unroll
+        for (int k = 0; k < EMBED; ++k) {
+            const float pv = pp[k];
+            row[k] = er[k] + pv;
+            row[EMBED + k] = ef[k] + pv;
+        }
+        row[40] = (float)q * 0.01f;
+        row[41] = (float)st * 0.5f;
+        row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
+        row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
+        row[44] = (rm != 0) ? 1.f : 0.f;
+    }
+}
+
+// v = A s1 + B s2 + C, then masked by s2 > 0
+__device__ __forceinline__ v4f load_transform(v4f s1, v4f s2, const float* coef, int c, int mask) {
+    v4f v = s1;
+    if (coef) {
+        const v4f A = *(const v4f*)(coef + c), B = *(const v4f*)(coef + CPAD + c), C = *(const v4f*)(coef + 2 * CPAD + c);
+        v = A * s1 + B * s2 + C;
+    }
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = s2[j] > 0.f ? v[j] : 0.f;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// T1: one layer-shaped step on the LDS-resident read
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
+    __shared__ float sred[2][2][CPAD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.x;
+    const int site = row / a.R;
+    const int L = a.L;
+    for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+    __syncthreads();
+    if (a.mode == 0) {
+        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
+        encode_rows(xs, LDS_S, HALO, 0, L, e, (size_t)row, site, L, tid);
+    } else {
+        const int vpr = a.s1_stride >> 2;                       // 16-byte vectors per position
+        const int n4 = L * vpr;
+        const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * a.s1_stride);
+        const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)row * L * a.s1_stride) : nullptr;
+        const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
+        for (int i = tid; i < n4; i += SEG_THREADS) {
+            const int p = i / vpr, c4 = i - p * vpr;
+            v4f v = load_transform(s1[i], s2 ? s2[i] : splat(0.f), a.coef, c4 * 4, a.mask_src2);
+            if (pl) v += pl[i];
+            *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    const int pos = lane & 15, kk = lane >> 4;
+    const int cq = wave & 3, ph = wave >> 2;
+    const int m_base = ph * MTW, cnt = ph ? MT - MTW : MTW;
+    int chb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) chb[n] = (cq * NT + n) * 16 + kk * 4;
+    v4f acc[MTW][NT];
+    if (a.w1) {
+        gv4f_ptr w = (gv4f_ptr)(a.w1) + (cq * NT) * 64 + lane;
+        const v4f first[NT] = {w[0], w[64]};
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = splat(0.f);
+        conv_gemm(acc, xs, w, first, a.kg, a.taps, a.dil, lane, m_base, cnt);
+    } else {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = (m < cnt) ? *(const v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]) : splat(0.f);
+    }
+    // ---- epilogue
+    const size_t rbase = (size_t)row * L * CPAD, sbase = (size_t)site * L * CPAD;
+    v4f s0[NT], s1v[NT], bias[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        s0[n] = splat(0.f); s1v[n] = splat(0.f);
+        bias[n] = a.bias1 ? *(const v4f*)(a.bias1 + chb[n]) : splat(0.f);
+    }
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int p = (m_base + m) * 16 + pos;
+        const bool live = (m < cnt) && (p < L);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            v4f v = splat(0.f);
+            if (live) {
+                const size_t o = (size_t)p * CPAD + chb[n];
+                v = acc[m][n] + bias[n];
+                if (a.add1) v += *(const v4f*)(a.add1 + rbase + o);
+                if (a.add2) v += *(const v4f*)(a.add2 + rbase + o);
+                if (a.addb) v += *(const v4f*)(a.addb + sbase + o);
+                if (a.relu_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (a.stats) {
+                    const v4f x = a.stat_aux ? *(const v4f*)(a.stat_aux + rbase + o) : v;
+                    s0[n] += v;
+                    s1v[n] += v * x;
+                }
+                if (a.out1) *(v4f*)(a.out1 + rbase + o) = v;
+            }
+            acc[m][n] = v;
+        }
+    }
+    if (a.stats) {
+        // sum over the 16 position lanes of a k-quarter, then over the two position halves (waves cq and cq + 4)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s0[n][j], y = s1v[n][j];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) { x += __shfl_xor(x, msk); y += __shfl_xor(y, msk); }
+                if (pos == 0) { sred[ph][0][chb[n] + j] = x; sred[ph][1][chb[n] + j] = y; }
+            }
+    }
+    if (a.w2 || a.stats) __syncthreads();                        // (also: every wave has finished reading the image)
+    if (a.stats && tid < 2 * CPAD) {
+        const int st = tid >> 7, ch = tid & (CPAD - 1);
+        a.stats[((size_t)row * 2 + st) * CPAD + ch] = sred[0][st][ch] + sred[1][st][ch];
+    }
+    if (a.w2) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            if (m < cnt) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) *(v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
+            }
+        }
+        gv4f_ptr wb = (gv4f_ptr)(a.w2) + lane;
+        v4f wbot[KGC];
+#pragma unroll
+        for (int g = 0; g < KGC; ++g) wbot[g] = wb[(g * 2 + (wave & 1)) * 64];
+        __syncthreads();
+        bottleneck<NWAVE>(xs, wbot, a.bias2, a.out2 + (size_t)row * L * HPAD, L, wave, lane);
+    }
+}
+
+void launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(train_row_kernel, dim3((unsigned)n_rows), dim3(SEG_THREADS), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// T2: weight gradients (contraction over positions)
+// ------------------------------------------------------------------------------------------------
+// Wave w owns output tile w of A (OWN_O) and every input tile of B and tap, or input tile w of B and both output tiles of
+// A (bottleneck: A is 32 wide).  MFMA k index = position: lane group kk supplies position 4 k4 + kk, so the two k-groups
+// of a 32-lane half read rows one apart: with the 144-float row stride those are 16 banks apart -- conflict-free ds_read_b32.
+template <int TAPS, bool OWN_O>
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(WgradArgs a) {
+    constexpr int BROWS = WG_CH + 2 * HALO;
+    constexpr int NB = OWN_O ? KGC : 1, NA = OWN_O ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float sa[WG_CH * WG_S];
+    __shared__ __attribute__((aligned(16))) float sb[BROWS * WG_S];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.L;
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int vpa = a.a_stride >> 2;
+    v4f acc[TAPS][NA][NB];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) acc[t][x][y] = splat(0.f);
+    v4f bsum = splat(0.f);
+    for (int i = tid; i < WG_CH * WG_S / 4; i += SEG_THREADS) ((v4f*)sa)[i] = splat(0.f);
+    const bool active = OWN_O ? (wave < a.o_tiles) : (wave < a.c_tiles);
+    for (int row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
+        const int site = row / a.R;
+        for (int p0 = 0; p0 < L; p0 += WG_CH) {
+            __syncthreads();                                     // the previous chunk's MFMAs are done with the images
+            // ---- A rows [p0, p0 + WG_CH)
+            {
+                const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * a.a_stride);
+                const v4f* s2 = a.a2 ? (const v4f*)(a.a2 + (size_t)row * L * a.a_stride) : nullptr;
+                for (int i = tid; i < WG_CH * vpa; i += SEG_THREADS) {
+                    const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                    v4f v = splat(0.f);
+                    if (p < L) {
+                        const size_t g = (size_t)p * vpa + c4;
+                        v = load_transform(s1[g], s2 ? s2[g] : splat(0.f), a.a_coef, c4 * 4, a.a_mask);
+                    }
+                    *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
+                    bsum += v;
+                }
+            }
+            // ---- B rows [p0 - HALO, p0 + WG_CH + HALO)
+            if (a.b_mode == 0) {
+                for (int i = tid; i < BROWS * WG_S / 4; i += SEG_THREADS) ((v4f*)sb)[i] = splat(0.f);
+                __syncthreads();
+                EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
+                encode_rows(sb, WG_S, 0, p0 - HALO, p0 + WG_CH + HALO, e, (size_t)row, site, L, tid);
+            } else {
+                const v4f* b1 = (const v4f*)(a.b1 + (size_t)row * L * CPAD);
+                const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
+                for (int i = tid; i < BROWS * (CPAD / 4); i += SEG_THREADS) {
+                    const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
+                    v4f v = splat(0.f);
+                    if (p >= 0 && p < L) {
+                        const size_t g = (size_t)p * (CPAD / 4) + c4;
+                        v = b1[g];
+                        if (a.b_coef) v = *(const v4f*)(a.b_coef + c4 * 4) * v + *(const v4f*)(a.b_coef + 2 * CPAD + c4 * 4);
+                        if (pl4) v += pl4[g];
+                    }
+                    *(v4f*)(sb + pl * WG_S + c4 * 4) = v;
+                }
+            }
+            __syncthreads();
+            if (active) {
+                for (int k4 = 0; k4 < WG_CH / 4; ++k4) {
+                    const int r = 4 * k4 + kk;
+                    float av[NA];
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) av[x] = sa[r * WG_S + 16 * (OWN_O ? wave : x) + i16];
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const float* brow = sb + (HALO + r + (t - TAPS / 2) * a.dil) * WG_S + i16;
+#pragma unroll
+                        for (int y = 0; y < NB; ++y) {
+                            if (OWN_O && y >= a.c_tiles) continue;
+                            const float bv = brow[16 * (OWN_O ? y : wave)];
+#pragma unroll
+                            for (int x = 0; x < NA; ++x) {
+                                if (!OWN_O && x >= a.o_tiles) continue;
+                                acc[t][x][y] = mfma16(av[x], bv, acc[t][x][y]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- partial results of this workgroup
+    const int OP = a.o_tiles * 16, CP = a.c_tiles * 16;
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
+                for (int y = 0; y < NB; ++y) {
+                    const int ot = OWN_O ? wave : x, ct = OWN_O ? y : wave;
+                    if (ot >= a.o_tiles || ct >= a.c_tiles) continue;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int o = 16 * ot + 4 * kk + jj, c = 16 * ct + i16;
+                        a.partial[(((size_t)blockIdx.x * TAPS + t) * OP + o) * CP + c] = acc[t][x][y][jj];
+                    }
+                }
+    }
+    // bias gradient: per-thread channel sums -> fixed-order sum over the threads that staged the same channels
+    __syncthreads();
+    float* scratch = sb;                                         // [SEG_THREADS][4]
+    *(v4f*)(scratch + tid * 4) = bsum;
+    __syncthreads();
+    if (tid < OP) {
+        const int c4 = tid >> 2, j = tid & 3;
+        float sum = 0.f;
+        for (int t = c4; t < SEG_THREADS; t += vpa) sum += scratch[t * 4 + j];
+        a.bias_partial[(size_t)blockIdx.x * OP + tid] = sum;
+    }
+}
+
+int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
+    const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
+    const dim3 grid((unsigned)wgs), blk(SEG_THREADS);
+    if (a.o_tiles <= 2 && a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, false>), grid, blk, 0, s, a);
+    else if (a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, true>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((train_wgrad_kernel<3, true>), grid, blk, 0, s, a);
+    return wgs;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
+                                                           int wgs, int taps, int OP, int CP, int n_out, int n_in,
+                                                           const int* __restrict__ cmap, float* g_w, float* g_b) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = taps * n_out * n_in;
+    if (idx < total) {
+        const int i = idx % n_in, o = (idx / n_in) % n_out, t = idx / (n_in * n_out);
+        const int c = cmap ? cmap[i] : i;
+        float sum = 0.f;
+        for (int w = 0; w < wgs; ++w) sum += partial[(((size_t)w * taps + t) * OP + o) * CP + c];
+        g_w[((size_t)o * n_in + i) * taps + t] = sum;
+    } else if (g_b && idx < total + n_out) {
+        const int o = idx - total;
+        float sum = 0.f;
+        for (int w = 0; w < wgs; ++w) sum += bias_partial[(size_t)w * OP + o];
+        g_b[o] = sum;
+    }
+}
+
+void launch_wgrad_reduce(const float* partial, const float* bias_partial, int wgs, int taps, int o_pad, int c_pad, int n_out,
+                         int n_in, const int* cmap, float* g_w, float* g_b, hipStream_t s) {
+    const int total = taps * n_out * n_in + n_out;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, partial, bias_partial, wgs, taps, o_pad,
+                       c_pad, n_out, n_in, cmap, g_w, g_b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel statistics: [row][2][CPAD] fp32 partials -> block partials in double -> BatchNorm coefficients
+// ------------------------------------------------------------------------------------------------
+constexpr int STAT_ROWS_PER_BLOCK = 32;
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ stats, int n_rows, double* __restrict__ bp) {
+    const int lo = blockIdx.x * STAT_ROWS_PER_BLOCK, hi = min(n_rows, lo + STAT_ROWS_PER_BLOCK);
+    double sum = 0.0;
+    for (int r = lo; r < hi; ++r) sum += (double)stats[(size_t)r * 2 * CPAD + threadIdx.x];
+    bp[(size_t)blockIdx.x * 2 * CPAD + threadIdx.x] = sum;
+}
+
+void launch_stats_partial(const float* stats, int n_rows, double* bp, int* n_blocks, hipStream_t s) {
+    const int nb = (n_rows + STAT_ROWS_PER_BLOCK - 1) / STAT_ROWS_PER_BLOCK;
+    *n_blocks = nb;
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(nb), dim3(2 * CPAD), 0, s, stats, n_rows, bp);
+}
+
+__global__ __launch_bounds__(CPAD) void bn_forward_finalize_kernel(const double* __restrict__ bp, int nb, double n_pos,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   int channels, float* coef, float* save_mean, float* save_invstd,
+                                                                   float* run_mean, float* run_var) {
+    const int ch = threadIdx.x;
+    float scale = 0.f, shift = 0.f;
+    if (ch < channels) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int b = 0; b < nb; ++b) { s0 += bp[(size_t)b * 2 * CPAD + ch]; s1 += bp[(size_t)b * 2 * CPAD + CPAD + ch]; }
+        const double mean = s0 / n_pos;
+        double var = s1 / n_pos - mean * mean;                  // biased variance normalises (nn.BatchNorm2d, training)
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + 1e-5);
+        scale = (float)((double)gamma[ch] * invstd);
+        shift = (float)((double)beta[ch] - mean * (double)gamma[ch] * invstd);
+        save_mean[ch] = (float)mean;
+        save_invstd[ch] = (float)invstd;
+        // running statistics: momentum 0.1, UNBIASED batch variance
+        run_mean[ch] = (float)(0.9 * (double)run_mean[ch] + 0.1 * mean);
+        run_var[ch] = (float)(0.9 * (double)run_var[ch] + 0.1 * var * (n_pos / (n_pos - 1.0)));
+    }
+    coef[ch] = scale;
+    coef[CPAD + ch] = 0.f;
+    coef[2 * CPAD + ch] = shift;
+}
+
+void launch_bn_forward_finalize(const double* bp, int n_blocks, double n_pos, const float* gamma, const float* beta, int channels,
+                                float* coef, float* save_mean, float* save_invstd, float* run_mean, float* run_var, hipStream_t s) {
+    hipLaunchKernelGGL(bn_forward_finalize_kernel, dim3(1), dim3(CPAD), 0, s, bp, n_blocks, n_pos, gamma, beta, channels, coef,
+                       save_mean, save_invstd, run_mean, run_var);
+}
+
+// da = gamma r (dn - dbeta/N - nhat dgamma/N),  nhat = (a - mean) r   =>   da = A dn + B a + C
+__global__ __launch_bounds__(CPAD) void bn_backward_coef_kernel(const double* __restrict__ bp, int nb, double n_pos,
+                                                                const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                                const float* __restrict__ save_invstd, int channels, int use_bn,
+                                                                float* coef, float* g_gamma, float* g_beta) {
+    const int ch = threadIdx.x;
+    float A = 0.f, B = 0.f, C = 0.f;
+    if (ch < channels) {
+        if (use_bn) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int b = 0; b < nb; ++b) { s0 += bp[(size_t)b * 2 * CPAD + ch]; s1 += bp[(size_t)b * 2 * CPAD + CPAD + ch]; }
+            const double mu = save_mean[ch], r = save_invstd[ch], g = gamma[ch];
+            const double dbeta = s0, dgamma = (s1 - mu * s0) * r;
+            g_gamma[ch] = (float)dgamma;
+            g_beta[ch] = (float)dbeta;
+            A = (float)(g * r);
+            const double Bd = -g * r * r * dgamma / n_pos;
+            B = (float)Bd;
+            C = (float)(-g * r * dbeta / n_pos - Bd * mu);
+        } else {
+            A = 1.f;
+        }
+    }
+    coef[ch] = A;
+    coef[CPAD + ch] = B;
+    coef[2 * CPAD + ch] = C;
+}
+
+void launch_bn_backward_coef(const double* bp, int n_blocks, double n_pos, const float* gamma, const float* save_mean,
+                             const float* save_invstd, int channels, int use_bn, float* coef, float* g_gamma, float* g_beta,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(bn_backward_coef_kernel, dim3(1), dim3(CPAD), 0, s, bp, n_blocks, n_pos, gamma, save_mean, save_invstd,
+                       channels, use_bn, coef, g_gamma, g_beta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_frag_kernel(float* __restrict__ dst, const float* __restrict__ src, int taps, int kg,
+                                                        int tiles, int n_out, int n_in, long long so, long long sc, long long st,
+                                                        int flip, const int* __restrict__ omap, const int* __restrict__ cmap) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)taps * kg * tiles * 256;
+    if (idx >= total) return;
+    const int sidx = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long long rest = idx >> 8;
+    const int n = (int)(rest % tiles); rest /= tiles;
+    const int g = (int)(rest % kg);
+    const int t = (int)(rest / kg);
+    int o = 16 * n + (lane & 15), c = 16 * g + 4 * (lane >> 4) + sidx;
+    float v = 0.f;
+    if (omap) o = (o < n_out) ? omap[o] : -1; else if (o >= n_out) o = -1;
+    if (cmap) c = (c < n_in) ? cmap[c] : -1; else if (c >= n_in) c = -1;
+    if (o >= 0 && c >= 0) v = src[(long long)o * so + (long long)c * sc + (long long)(flip ? taps - 1 - t : t) * st];
+    dst[idx] = v;
+}
+
+void launch_pack_frag(float* dst, const float* src, int taps, int kg, int tiles, int n_out, int n_in, long long so, long long sc,
+                      long long st, int flip, const int* omap, const int* cmap, hipStream_t s) {
+    const long long total = (long long)taps * kg * tiles * 256;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dst, src, taps, kg, tiles, n_out, n_in,
+                       so, sc, st, flip, omap, cmap);
+}
+
+// highway kernel fragment order: dst[g = 2p + (c>>4)][n][lane][s] = Wc[o = 16n + (lane&15)][c = 16(g&1) + 4(lane>>4) + s][p]
+__global__ __launch_bounds__(256) void pack_wc_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * L * 2 * 256) return;
+    const int sidx = idx & 3, lane = (idx >> 2) & 63, n = (idx >> 8) & 1, g = idx >> 9;
+    const int o = 16 * n + (lane & 15), c = 16 * (g & 1) + 4 * (lane >> 4) + sidx, p = g >> 1;
+    dst[idx] = (o < H && c < H) ? src[((size_t)o * H + c) * L + p] : 0.f;
+}
+
+// WcT[p][c][o] = Wc[o][c][p], zero-padded to HPAD x HPAD (the highway backward reads 32 consecutive o per (p, c))
+__global__ __launch_bounds__(256) void pack_wct_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L * HPAD * HPAD) return;
+    const int o = idx & 31, c = (idx >> 5) & 31, p = idx >> 10;
+    dst[idx] = (o < H && c < H) ? src[((size_t)o * H + c) * L + p] : 0.f;
+}
+
+void launch_pack_wct(float* dst, const float* src, int H, int L, hipStream_t s) {
+    hipLaunchKernelGGL(pack_wct_kernel, dim3((L * HPAD * HPAD + 255) / 256), dim3(256), 0, s, dst, src, H, L);
+}
+
+// dst[i] = i < n ? src[i] : 0 for i < n_pad   (biases padded to the kernels' channel capacity)
+__global__ __launch_bounds__(256) void pad_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, int n_pad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pad) dst[i] = i < n ? src[i] : 0.f;
+}
+
+void launch_pad_copy(float* dst, const float* src, int n, int n_pad, hipStream_t s) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, dst, src, n, n_pad);
+}
+
+void launch_pack_wc(float* dst, const float* src, int H, int L, hipStream_t s) {
+    hipLaunchKernelGGL(pack_wc_kernel, dim3((2 * L * 2 * 256 + 255) / 256), dim3(256), 0, s, dst, src, H, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// final max + mean pool backward (dl4vc/model.py:824-839): the max's gradient goes to the FIRST read attaining it
+// (torch's max_pool2d keeps the first index on ties: all-padding rows of a pileup are identical)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_pool_bwd_kernel(const v4f* __restrict__ y, const float* __restrict__ dfeat, long long fs,
+                                                             v4f* __restrict__ g, int R, int L, int C) {
+    constexpr int PT = 32, PS = PT + 1;
+    __shared__ float dmax[CPAD * PS], dmean[CPAD * PS];
+    const int pt = blockIdx.x, site = blockIdx.y, tid = threadIdx.x;
+    const float* row = dfeat + (size_t)site * fs;
+    for (int idx = tid; idx < CPAD * PT; idx += 256) {
+        const int c = idx / PT, pp = idx % PT, p = pt * PT + pp;
+        const bool ok = c < C && p < L;
+        dmax[c * PS + pp] = ok ? row[(size_t)c * L + p] : 0.f;
+        dmean[c * PS + pp] = ok ? row[(size_t)C * L + (size_t)c * L + p] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = tid & 31, pl = tid >> 5;
+    const int n4 = L * (CPAD / 4);
+    const float inv = 1.f / (float)R;
+#pragma unroll
+    for (int part = 0; part < PT / 8; ++part) {
+        const int pp = part * 8 + pl, p = pt * PT + pp;
+        if (p >= L) continue;
+        const size_t off = (size_t)p * (CPAD / 4) + c4;
+        v4f mx = y[((size_t)site * R) * n4 + off];
+        int arg[4] = {0, 0, 0, 0};
+        for (int r = 1; r < R; ++r) {
+            const v4f v = y[((size_t)site * R + r) * n4 + off];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] > mx[j]) { mx[j] = v[j]; arg[j] = r; }
+        }
+        v4f dm, da;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dm[j] = dmax[(c4 * 4 + j) * PS + pp]; da[j] = dmean[(c4 * 4 + j) * PS + pp] * inv; }
+        for (int r = 0; r < R; ++r) {
+            v4f o = da;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += (arg[j] == r) ? dm[j] : 0.f;
+            g[((size_t)site * R + r) * n4 + off] = o;
+        }
+    }
+}
+
+void launch_final_pool_bwd(const float* y, const float* dfeat, long long fs, float* g, int n_sites, int R, int L, int C, hipStream_t s) {
+    hipLaunchKernelGGL(final_pool_bwd_kernel, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const v4f*)y, dfeat, fs, (v4f*)g, R, L, C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// highway compression backward (dl4vc/model.py:776-777,859): per layer  hw[row][o] = sum_{p,c} Wc[o][c][p] h[row][p][c]
+// ------------------------------------------------------------------------------------------------
+// dhw[row][o] = dfeat_hw * (feat_hw > 0)   (the ReLU sits on the concatenated highways, model.py:859)
+__device__ __forceinline__ float dhw_of(const float* dfeat, const float* feat, long long fs, int feat_off, int layer, int H, int R,
+                                        int row, int o) {
+    const int site = row / R, r = row - site * R;
+    const size_t i = (size_t)site * fs + feat_off + (size_t)layer * H * R + (size_t)o * R + r;
+    return feat[i] > 0.f ? dfeat[i] : 0.f;
+}
+
+constexpr int HB_ROWS = 8;
+__global__ __launch_bounds__(256) void highway_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
+                                                          int feat_off, const float* __restrict__ wc, long long wc_layer,
+                                                          float* __restrict__ dh, long long dh_layer, int n_rows, int R, int L, int H) {
+    __shared__ float d[HB_ROWS][HPAD];
+    const int layer = blockIdx.y, row0 = blockIdx.x * HB_ROWS, tid = threadIdx.x;
+    {
+        const int rr = tid >> 5, o = tid & 31, row = row0 + rr;
+        d[rr][o] = (row < n_rows && o < H) ? dhw_of(dfeat, feat, fs, feat_off, layer, H, R, row, o) : 0.f;
+    }
+    __syncthreads();
+    const float* w = wc + (size_t)layer * wc_layer;             // transposed copy WcT[p][c][o] (launch_pack_wct): 128-byte runs per thread
+    for (int e = tid; e < L * HPAD; e += 256) {
+        float acc[HB_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < HB_ROWS; ++rr) acc[rr] = 0.f;
+        const v4f* wv4 = (const v4f*)(w + (size_t)e * HPAD);
+#pragma unroll
+        for (int o4 = 0; o4 < HPAD / 4; ++o4) {
+            const v4f wv = wv4[o4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rr = 0; rr < HB_ROWS; ++rr) acc[rr] = fmaf(d[rr][o4 * 4 + j], wv[j], acc[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < HB_ROWS; ++rr)
+            if (row0 + rr < n_rows) dh[(size_t)layer * dh_layer + (size_t)(row0 + rr) * L * HPAD + e] = acc[rr];
+    }
+}
+
+void launch_highway_bwd(const float* dfeat, const float* feat, long long fs, int feat_off, const float* wc, long long wc_layer,
+                        float* dh, long long dh_layer, int n_sites, int R, int L, int H, int layers, hipStream_t s) {
+    const int n_rows = n_sites * R;
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3((n_rows + HB_ROWS - 1) / HB_ROWS, layers), dim3(256), 0, s, dfeat, feat, fs, feat_off, wc,
+                       wc_layer, dh, dh_layer, n_rows, R, L, H);
+}
+
+// gWc[o][c][p] partial over a block of rows: thread = one (p, c) element, 32 outputs in registers
+constexpr int HW_SPLITS = 8;
+__global__ __launch_bounds__(256) void highway_wgrad_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
+                                                            int feat_off, int layer, const float* __restrict__ h, float* __restrict__ partial,
+                                                            int n_rows, int R, int L, int H) {
+    __shared__ float d[32][HPAD];
+    const int tid = threadIdx.x, split = blockIdx.y;
+    const int e = blockIdx.x * 256 + tid, n_e = L * HPAD;
+    const int per = (n_rows + HW_SPLITS - 1) / HW_SPLITS, lo = split * per, hi = min(n_rows, lo + per);
+    float acc[HPAD];
+#pragma unroll
+    for (int o = 0; o < HPAD; ++o) acc[o] = 0.f;
+    for (int r0 = lo; r0 < hi; r0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * HPAD; i += 256) {
+            const int rr = i >> 5, o = i & 31, row = r0 + rr;
+            d[rr][o] = (row < hi && o < H) ? dhw_of(dfeat, feat, fs, feat_off, layer, H, R, row, o) : 0.f;
+        }
+        __syncthreads();
+        if (e < n_e) {
+            const int nr = min(32, hi - r0);
+            for (int rr = 0; rr < nr; ++rr) {
+                const float hv = h[(size_t)(r0 + rr) * n_e + e];
+#pragma unroll
+                for (int o = 0; o < HPAD; ++o) acc[o] = fmaf(d[rr][o], hv, acc[o]);
+            }
+        }
+    }
+    if (e < n_e) {
+#pragma unroll
+        for (int o = 0; o < HPAD; ++o) partial[((size_t)split * HPAD + o) * n_e + e] = acc[o];
+    }
+}
+
+__global__ __launch_bounds__(256) void highway_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ g_wc, int L, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;             // over (o, c, p) of the torch layout (H, H, 1, L)
+    if (idx >= H * H * L) return;
+    const int p = idx % L, c = (idx / L) % H, o = idx / (L * H);
+    const int n_e = L * HPAD, e = p * HPAD + c;
+    float sum = 0.f;
+    for (int sp = 0; sp < HW_SPLITS; ++sp) sum += partial[((size_t)sp * HPAD + o) * n_e + e];
+    g_wc[idx] = sum;
+}
+
+__global__ __launch_bounds__(64) void highway_bias_grad_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
+                                                               int feat_off, float* __restrict__ g_bc, long long bc_layer, int n_rows, int R, int H) {
+    const int layer = blockIdx.x, o = threadIdx.x;
+    if (o >= H) return;
+    float sum = 0.f;
+    for (int row = 0; row < n_rows; ++row) sum += dhw_of(dfeat, feat, fs, feat_off, layer, H, R, row, o);
+    g_bc[(size_t)layer * bc_layer + o] = sum;
+}
+
+void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, int feat_off, const float* h, long long h_layer,
+                          float* partial, float* g_wc, long long wc_layer, float* g_bc, int n_sites, int R, int L, int H, int layers,
+                          int layer_stride_b, hipStream_t s) {
+    const int n_rows = n_sites * R, n_e = L * HPAD;
+    for (int l = 0; l < layers; ++l) {
+        hipLaunchKernelGGL(highway_wgrad_kernel, dim3((n_e + 255) / 256, HW_SPLITS), dim3(256), 0, s, dfeat, feat, fs, feat_off, l,
+                           h + (size_t)l * h_layer, partial, n_rows, R, L, H);
+        hipLaunchKernelGGL(highway_wgrad_reduce_kernel, dim3((H * H * L + 255) / 256), dim3(256), 0, s, partial, g_wc + (size_t)l * wc_layer, L, H);
+    }
+    hipLaunchKernelGGL(highway_bias_grad_kernel, dim3(layers), dim3(64), 0, s, dfeat, feat, fs, feat_off, g_bc, (long long)layer_stride_b,
+                       n_rows, R, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding gradient (dl4vc/model.py:143-145,450-451): two lookups (reads: B*L*R indices, ref: B*L indices), each with
+// padding_idx 0 and scale_grad_by_freq -- a row's gradient is the MEAN over its occurrences in that lookup
+// ------------------------------------------------------------------------------------------------
+constexpr int EMB_W = 2 * EMBED + 2;                            // per token: 20 read-lookup sums, 20 ref-lookup sums, 2 counts
+__global__ __launch_bounds__(512) void embedding_partial_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ reads,
+                                                                const uint8_t* __restrict__ ref, int R, int L, float* __restrict__ partial) {
+    __shared__ uint8_t tok[256], rtk[256];
+    const int row = blockIdx.x, site = row / R, tid = threadIdx.x;
+    if (tid < L) { tok[tid] = min((int)reads[(size_t)row * L + tid], VOCAB - 1); rtk[tid] = min((int)ref[(size_t)site * L + tid], VOCAB - 1); }
+    __syncthreads();
+    if (tid < VOCAB * EMB_W) {
+        const int k = tid / EMB_W, e = tid % EMB_W;
+        const float* x = dx0 + (size_t)row * L * CPAD;
+        float sum = 0.f;
+        if (e < EMBED) { for (int p = 0; p < L; ++p) if (tok[p] == k) sum += x[(size_t)p * CPAD + e]; }
+        else if (e < 2 * EMBED) { for (int p = 0; p < L; ++p) if (rtk[p] == k) sum += x[(size_t)p * CPAD + e]; }
+        else if (e == 2 * EMBED) { for (int p = 0; p < L; ++p) sum += (tok[p] == k); }
+        else { if (row == site * R) for (int p = 0; p < L; ++p) sum += (rtk[p] == k); }       // the ref lookup: once per site
+        partial[(size_t)row * VOCAB * EMB_W + tid] = sum;
+    }
+}
+
+__global__ __launch_bounds__(512) void embedding_reduce_kernel(const float* __restrict__ partial, int n_rows, float* __restrict__ g_emb) {
+    __shared__ double tot[VOCAB * EMB_W];
+    const int tid = threadIdx.x;
+    if (tid < VOCAB * EMB_W) {
+        double sum = 0.0;
+        for (int r = 0; r < n_rows; ++r) sum += (double)partial[(size_t)r * VOCAB * EMB_W + tid];
+        tot[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < VOCAB * EMBED) {
+        const int k = tid / EMBED, e = tid % EMBED;
+        double g = 0.0;
+        if (k != 0) {                                            // padding_idx = base_enum['pad'] = 0
+            const double cr = tot[k * EMB_W + 2 * EMBED], cf = tot[k * EMB_W + 2 * EMBED + 1];
+            if (cr > 0.0) g += tot[k * EMB_W + e] / cr;
+            if (cf > 0.0) g += tot[k * EMB_W + EMBED + e] / cf;
+        }
+        g_emb[tid] = (float)g;
+    }
+}
+
+void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
+                           float* g_emb, hipStream_t s) {
+    const int n_rows = n_sites * R;
+    hipLaunchKernelGGL(embedding_partial_kernel, dim3(n_rows), dim3(512), 0, s, dx0, reads, ref, R, L, partial);
+    hipLaunchKernelGGL(embedding_reduce_kernel, dim3(1), dim3(512), 0, s, partial, n_rows, g_emb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FC stack: tiled MFMA GEMM  C[m][n] = sum_k opA(m,k) opB(n,k) (+ bias[n], ReLU)
+// 128 x 128 x 32 tiles through LDS as in the inference fc_kernel; an operand that is K-slow in memory (X[k*ld + i]: the
+// transposed uses of the backward pass) is staged as [k][i] rows and its fragments are read with four ds_read_b32 (row
+// stride 132: the two k-groups of a 32-lane half sit 4 rows = 16 banks apart) instead of one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 128, GK = 32, GS_KC = GK + 8, GS_KS = GM + 4;
+template <bool A_KSLOW, bool B_KSLOW>
+__global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
+                                                   const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N,
+                                                   int K, int relu, int tiles_n) {
+    constexpr int SZA = A_KSLOW ? GK * GS_KS : GM * GS_KC, SZB = B_KSLOW ? GK * GS_KS : GN * GS_KC;
+    __shared__ __attribute__((aligned(16))) float sa[2][SZA], sb[2][SZB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int bm = (blockIdx.x / tiles_n) * GM, bn = (blockIdx.x % tiles_n) * GN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+    const int M4 = (M + 3) & ~3, N4 = (N + 3) & ~3;
+    v4f ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (A_KSLOW) {                                       // rows k0 + (tid >> 5) + 16 i, columns bm + 4 (tid & 31)
+                const int k = k0 + (tid >> 5) + 16 * i, m = bm + 4 * (tid & 31);
+                ra[i] = (k < K && m < M4) ? *(const v4f*)(A + (size_t)k * lda + m) : splat(0.f);
+            } else {                                             // rows bm + (tid >> 3) + 64 i, k = k0 + 4 (tid & 7)
+                const int m = min(bm + (tid >> 3) + 64 * i, M - 1), k = k0 + 4 * (tid & 7);
+                ra[i] = (k < K) ? *(const v4f*)(A + (size_t)m * lda + k) : splat(0.f);
+            }
+            if (B_KSLOW) {
+                const int k = k0 + (tid >> 5) + 16 * i, n = bn + 4 * (tid & 31);
+                rb[i] = (k < K && n < N4) ? *(const v4f*)(B + (size_t)k * ldb + n) : splat(0.f);
+            } else {
+                const int n = min(bn + (tid >> 3) + 64 * i, N - 1), k = k0 + 4 * (tid & 7);
+                rb[i] = (k < K) ? *(const v4f*)(B + (size_t)n * ldb + k) : splat(0.f);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (A_KSLOW) *(v4f*)(&sa[buf][((tid >> 5) + 16 * i) * GS_KS + 4 * (tid & 31)]) = ra[i];
+            else *(v4f*)(&sa[buf][((tid >> 3) + 64 * i) * GS_KC + 4 * (tid & 7)]) = ra[i];
+            if (B_KSLOW) *(v4f*)(&sb[buf][((tid >> 5) + 16 * i) * GS_KS + 4 * (tid & 31)]) = rb[i];
+            else *(v4f*)(&sb[buf][((tid >> 3) + 64 * i) * GS_KC + 4 * (tid & 7)]) = rb[i];
+        }
+    };
+    v4f acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = splat(0.f);
+    const int KT = (K + GK - 1) / GK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) gload((kt + 1) * GK);
+#pragma unroll
+        for (int g = 0; g < GK / 16; ++g) {
+            v4f a[4], w[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (A_KSLOW) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) a[i][sidx] = sa[cur][(16 * g + 4 * kk + sidx) * GS_KS + wm + 16 * i + r16];
+                } else {
+                    a[i] = *(const v4f*)(&sa[cur][(wm + 16 * i + r16) * GS_KC + 16 * g + 4 * kk]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (B_KSLOW) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) w[j][sidx] = sb[cur][(16 * g + 4 * kk + sidx) * GS_KS + wn + 16 * j + r16];
+                } else {
+                    w[j] = *(const v4f*)(&sb[cur][(wn + 16 * j + r16) * GS_KC + 16 * g + 4 * kk]);
+                }
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i][sidx], w[j][sidx], acc[i][j]);
+        }
+        if (kt + 1 < KT) sstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn + j * 16 + r16;
+        if (n >= N) continue;
+        const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = bm + wm + i * 16 + kk * 4 + jj;
+                if (m < M) {
+                    float v = acc[i][j][jj] + b;
+                    if (relu) v = fmaxf(v, 0.f);
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+    }
+}
+
+void launch_gemm(const float* A, long long lda, int a_kslow, const float* B, long long ldb, int b_kslow, const float* bias,
+                 float* C, long long ldc, int M, int N, int K, int relu, hipStream_t s) {
+    const int tiles_m = (M + GM - 1) / GM, tiles_n = (N + GN - 1) / GN;
+    const dim3 grid((unsigned)(tiles_m * tiles_n)), blk(512);
+    if (!a_kslow && !b_kslow) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
+    else if (!a_kslow && b_kslow) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
+    else if (a_kslow && !b_kslow) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise pieces of the FC stack
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, float scale,
+                                                      float* __restrict__ y, int rows, int cols, long long ld) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows * cols) return;
+    const int r = (int)(idx / cols), c = (int)(idx % cols);
+    const float m = mask ? (float)mask[idx] * scale : 1.f;
+    y[(size_t)r * ld + c] = x[(size_t)r * ld + c] * m;
+}
+
+void launch_dropout(const float* x, const uint8_t* mask, float scale, float* y, int rows, int cols, long long ld, hipStream_t s) {
+    const long long n = (long long)rows * cols;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, mask, scale, y, rows, cols, ld);
+}
+
+__global__ __launch_bounds__(256) void dropout_relu_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float scale,
+                                                               const float* __restrict__ act, int relu, float* __restrict__ dx, int rows,
+                                                               int cols, long long ld) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows * cols) return;
+    const int r = (int)(idx / cols), c = (int)(idx % cols);
+    const size_t o = (size_t)r * ld + c;
+    float v = dy[o] * (mask ? (float)mask[idx] * scale : 1.f);
+    if (relu && !(act[o] > 0.f)) v = 0.f;
+    dx[o] = v;
+}
+
+void launch_dropout_relu_bwd(const float* dy, const uint8_t* mask, float scale, const float* act, int relu, float* dx, int rows,
+                             int cols, long long ld, hipStream_t s) {
+    const long long n = (long long)rows * cols;
+    hipLaunchKernelGGL(dropout_relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, mask, scale, act, relu, dx, rows,
+                       cols, ld);
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int rows, int cols, long long ld, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float sum = 0.f;
+    for (int r = 0; r < rows; ++r) sum += x[(size_t)r * ld + c];
+    out[c] = sum;
+}
+
+void launch_colsum(const float* x, int rows, int cols, long long ld, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, x, rows, cols, ld, out);
+}
+
+// counter-based keep mask (splitmix64 of (seed, stream, index)): NOT torch's generator -- the reference's masks are
+// irreproducible outside torch; parity tests pass the reference's recorded masks explicitly instead
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long long n, float p, unsigned long long seed,
+                                                           unsigned long long stream_id) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (stream_id + 1) + (unsigned long long)idx * 0xD1342543DE82EF95ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    mask[idx] = u >= p ? 1 : 0;
+}
+
+void launch_dropout_mask(uint8_t* mask, long long n, float p, unsigned long long seed, unsigned long long stream_id, hipStream_t s) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mask, n, p, seed, stream_id);
+}
+
+// ------------------------------------------------------------------------------------------------
+// heads + losses + their gradients with respect to the 27 head outputs: ONE workgroup (batch-wide normalisers)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_neg_abs(float x) { return log1pf(expf(-fabsf(x))); }
+
+// SoftBCEWithLogitsFocalLoss (objectives.py:77-112) of one site: n classes, logits x, target index tgt, example weight wgt,
+// category weights pw (already divided by their sum).  Returns the site's loss; dx = d(site loss)/dx; *close = the flag.
+__device__ float focal_site(const float* x, int n, int tgt, float wgt, const float* pw, float eps, float window, float alpha,
+                            float gamma, float* dx, int* close) {
+    float mx = x[0];
+    for (int j = 1; j < n; ++j) mx = fmaxf(mx, x[j]);
+    float p[3], den = 0.f;
+    for (int j = 0; j < n; ++j) { p[j] = expf(x[j] - mx); den += p[j]; }
+    float loss = 0.f, dist = 0.f, ce[3], fw[3], dfw_dp[3];
+    for (int j = 0; j < n; ++j) {
+        p[j] = fminf(fmaxf(p[j] / den, 0.f), 1.f);
+        const float y = (j == tgt) ? 1.f - eps : eps / (float)(n - 1);
+        ce[j] = wgt * (fmaxf(x[j], 0.f) - x[j] * y + softplus_neg_abs(x[j]));          // BCE-with-logits, reduction none
+        const float pt = y * p[j] + (1.f - y) * (1.f - p[j]);
+        const float om = 1.f - pt;
+        fw[j] = powf(om, gamma) * pw[j];
+        // d fw / d p_j = pw gamma (1 - pt)^(gamma - 1) * -(2y - 1)
+        dfw_dp[j] = (gamma == 0.f) ? 0.f : pw[j] * gamma * powf(om, gamma - 1.f) * -(2.f * y - 1.f);
+        loss += alpha * fw[j] * ce[j];
+        dist += fabsf(p[j] - y);
+    }
+    *close = (dist * 0.5f) <= eps * window;
+    // dL/dx_k = alpha [ fw_k wgt (sigmoid(x_k) - y_k) + sum_j ce_j dfw_j/dp_j p_j (delta_jk - p_k) ]
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += ce[j] * dfw_dp[j] * p[j];
+    for (int k = 0; k < n; ++k) {
+        const float y = (k == tgt) ? 1.f - eps : eps / (float)(n - 1);
+        const float sig = 1.f / (1.f + expf(-x[k]));
+        dx[k] = alpha * (fw[k] * wgt * (sig - y) + ce[k] * dfw_dp[k] * p[k] - p[k] * s);
+    }
+    return loss;
+}
+
+__device__ const float BASE_CW[VOCAB] = {0.001f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.001f, 0.001f, 1.f, 0.001f};      // trainer.py:312-313
+
+__global__ __launch_bounds__(256) void heads_loss_kernel(LossArgs a, float* site_terms) {
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    // ---- head outputs (model.py:919-921,953-958) and the cross-entropy normalisers sum_b w[y_b]
+    float wsum_b = 0.f, wsum_r = 0.f;
+    for (int b = tid; b < a.B; b += 256) {
+        const float* x = a.hidden + (size_t)b * a.hid_stride;
+        for (int t = 0; t < NHEAD; ++t) {
+            const float* w = a.wh + (size_t)t * a.hid;
+            float acc = 0.f;
+            for (int k = 0; k < a.hid; ++k) acc = fmaf(x[k], w[k], acc);
+            a.logits[(size_t)b * NHEAD + t] = acc + a.bh[t];
+        }
+        wsum_b += BASE_CW[min((int)a.var_base[b], VOCAB - 1)];
+        wsum_r += BASE_CW[min((int)a.var_ref[b], VOCAB - 1)];
+    }
+    red[0][tid] = wsum_b; red[1][tid] = wsum_r;
+    __syncthreads();
+    if (tid < 2) {
+        float sum = 0.f;
+        for (int i = 0; i < 256; ++i) sum += red[tid][i];
+        red[tid][0] = sum;
+    }
+    __syncthreads();
+    const float wb_tot = red[0][0], wr_tot = red[1][0];
+    const float invB = 1.f / (float)a.B;
+    const float pw2[2] = {a.fp_weight / (a.fp_weight + 1.f), 1.f / (a.fp_weight + 1.f)};
+    const float pw3[3] = {a.fp_weight / (a.fp_weight + 2.f), 1.f / (a.fp_weight + 2.f), 1.f / (a.fp_weight + 2.f)};
+    for (int b = tid; b < a.B; b += 256) {
+        const float* z = a.logits + (size_t)b * NHEAD;
+        float* d = a.dlogits + (size_t)b * NHEAD;
+        float* term = site_terms + (size_t)b * 8;
+        const float wgt = a.weight[b];
+        // Bin: target = label <= 1 (trainer.py:134); VT: target = var_type
+        float dx[3];
+        int cl;
+        const float lb = focal_site(z, 2, a.label[b] <= 1 ? 1 : 0, wgt, pw2, a.label_smoothing, a.close_window, a.focal_alpha,
+                                    a.focal_gamma, dx, &cl);
+        a.close[b * 2] = (uint8_t)cl;
+        d[0] = dx[0] * invB * a.binary_weight; d[1] = dx[1] * invB * a.binary_weight;
+        const float lv = focal_site(z + 2, 3, a.var_type[b], wgt, pw3, a.label_smoothing, a.close_window, a.focal_alpha,
+                                    a.focal_gamma, dx, &cl);
+        a.close[b * 2 + 1] = (uint8_t)cl;
+        for (int j = 0; j < 3; ++j) d[2 + j] = dx[j] * invB * a.aux_weight;
+        // AF: F.binary_cross_entropy(sigmoid(z), t, weight) (trainer.py:309; log clamped at -100 as torch does)
+        const float af = 1.f / (1.f + expf(-z[5])), t_af = a.allele_freq[b];
+        const float l_af = -wgt * (t_af * fmaxf(logf(af), -100.f) + (1.f - t_af) * fmaxf(log1pf(-af), -100.f));
+        d[5] = wgt * (af - t_af) * invB * a.aux_weight * a.aux_allele_weight;
+        // coverage: F.mse_loss(leaky_relu(z), cov / 100) (trainer.py:141,310)
+        const float cv = z[6] > 0.f ? z[6] : 0.01f * z[6], t_cv = a.coverage[b] * 0.01f;
+        const float l_cv = (cv - t_cv) * (cv - t_cv);
+        d[6] = 2.f * (cv - t_cv) * (z[6] > 0.f ? 1.f : 0.01f) * invB * a.aux_weight;
+        // bases: F.cross_entropy(., weight) = sum_b w[y] nll / sum_b w[y]  (trainer.py:312-313)
+        float l_vb = 0.f, l_vr = 0.f;
+        for (int hd = 0; hd < 2; ++hd) {
+            const float* v = z + 7 + hd * VOCAB;
+            const int y = min((int)(hd ? a.var_ref[b] : a.var_base[b]), VOCAB - 1);
+            const float wy = BASE_CW[y], tot = hd ? wr_tot : wb_tot;
+            float mx = v[0];
+            for (int j = 1; j < VOCAB; ++j) mx = fmaxf(mx, v[j]);
+            float den = 0.f;
+            for (int j = 0; j < VOCAB; ++j) den += expf(v[j] - mx);
+            const float lse = mx + logf(den);
+            (hd ? l_vr : l_vb) = wy * (lse - v[y]);
+            for (int j = 0; j < VOCAB; ++j)
+                d[7 + hd * VOCAB + j] = wy * (expf(v[j] - lse) - (j == y ? 1.f : 0.f)) / tot * a.aux_weight * a.aux_bases_weight;
+        }
+        term[0] = lb; term[1] = lv; term[2] = l_af; term[3] = l_cv; term[4] = l_vb; term[5] = l_vr;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 6) {
+        float sum = 0.f;
+        for (int b = 0; b < a.B; ++b) sum += site_terms[(size_t)b * 8 + tid];
+        red[0][tid] = tid < 4 ? sum * invB : sum / (tid == 4 ? wb_tot : wr_tot);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float bin = red[0][0], vt = red[0][1], af = red[0][2], cov = red[0][3], vb = red[0][4], vr = red[0][5];
+        a.losses[1] = bin; a.losses[2] = vt; a.losses[3] = af; a.losses[4] = cov; a.losses[5] = vb; a.losses[6] = vr;
+        a.losses[0] = bin * a.binary_weight + (vt + af * a.aux_allele_weight + cov + (vb + vr) * a.aux_bases_weight) * a.aux_weight;   // trainer.py:426-427
+    }
+}
+
+void launch_heads_loss(const LossArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(256), 0, s, a, a.site_terms);
+}
+
+__global__ __launch_bounds__(256) void heads_bwd_hidden_kernel(const float* __restrict__ dl, const float* __restrict__ wh, int hid,
+                                                               int hid_stride, float* __restrict__ dh) {
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < hid; k += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < NHEAD; ++j) acc = fmaf(dl[(size_t)b * NHEAD + j], wh[(size_t)j * hid + k], acc);
+        dh[(size_t)b * hid_stride + k] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void heads_bwd_weight_kernel(const float* __restrict__ dl, const float* __restrict__ hidden, int B, int hid,
+                                                               int hid_stride, float* __restrict__ gwh, float* __restrict__ gbh) {
+    const int j = blockIdx.x;
+    for (int k = threadIdx.x; k < hid; k += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(dl[(size_t)b * NHEAD + j], hidden[(size_t)b * hid_stride + k], acc);
+        gwh[(size_t)j * hid + k] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += dl[(size_t)b * NHEAD + j];
+        gbh[j] = acc;
+    }
+}
+
+void launch_heads_bwd(const float* dlogits, const float* hidden, const float* wh, int B, int hid, int hid_stride, float* dhidden,
+                      float* gwh, float* gbh, hipStream_t s) {
+    hipLaunchKernelGGL(heads_bwd_hidden_kernel, dim3(B), dim3(256), 0, s, dlogits, wh, hid, hid_stride, dhidden);
+    hipLaunchKernelGGL(heads_bwd_weight_kernel, dim3(NHEAD), dim3(256), 0, s, dlogits, hidden, B, hid, hid_stride, gwh, gbh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam (trainer.py:437-439; torch.optim.Adam, no weight decay)
+// ------------------------------------------------------------------------------------------------
+constexpr int SUMSQ_PER_BLOCK = 256 * 64;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ bp) {
+    __shared__ double red[256];
+    const long long lo = (long long)blockIdx.x * SUMSQ_PER_BLOCK;
+    double sum = 0.0;
+    for (int i = 0; i < 64; ++i) {
+        const long long idx = lo + (long long)i * 256 + threadIdx.x;
+        if (idx < n) { const double v = g[idx]; sum += v * v; }
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bp[blockIdx.x] = red[0];
+}
+
+void launch_sumsq(const float* g, long long n, double* block_partials, int* n_blocks, hipStream_t s) {
+    const int nb = (int)((n + SUMSQ_PER_BLOCK - 1) / SUMSQ_PER_BLOCK);
+    *n_blocks = nb;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, g, n, block_partials);
+}
+
+__global__ __launch_bounds__(64) void clip_coef_kernel(const double* __restrict__ bp, int nb, float clip, float* out) {
+    if (threadIdx.x != 0) return;
+    double sum = 0.0;
+    for (int i = 0; i < nb; ++i) sum += bp[i];
+    const float norm = (float)sqrt(sum);
+    float coef = 1.f;
+    if (clip > 0.f) coef = fminf(1.f, clip / (norm + 1e-6f));
+    out[0] = norm;
+    out[1] = coef;
+}
+
+void launch_clip_coef(const double* block_partials, int n_blocks, float clip, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, s, block_partials, n_blocks, clip, out);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   long long n, const float* __restrict__ clip_out, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const float gi = g[idx] * clip_out[1];
+    const float mi = b1 * m[idx] + (1.f - b1) * gi;
+    const float vi = b2 * v[idx] + (1.f - b2) * gi * gi;
+    m[idx] = mi;
+    v[idx] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[idx] = p[idx] - (lr / bc1) * (mi / denom);
+}
+
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, const float* clip_out, float lr, float b1, float b2,
+                 float eps, float bc1, float bc2, hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, clip_out, lr, b1, b2, eps, bc1, bc2);
+}
+
+}  // namespace dan

@@ -46,6 +46,23 @@ def test_loader_header_symbols_exported():
         assert hasattr(nl, n), n
 
 
+def test_training_header_symbols_exported(lib):
+    """include/dl4vc_dan_train.h: every declared entry point is exported and bound."""
+    from dl4vc_amd import train
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dl4vc_dan_train.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(dan_train_[a-z_]+)\s*\(", text)))
+    assert set(names) == set(train.TRAIN_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+    body = re.search(r"typedef struct dan_train_hyper \{(.*?)\} dan_train_hyper;", text, flags=re.S).group(1)
+    fields = []
+    for decl in re.findall(r"float\s+([a-z0-9_, ]+);", body):
+        fields += [f.strip() for f in decl.split(",")]
+    assert fields == [f[0] for f in train._CHyper._fields_]
+    body = re.search(r"typedef struct dan_train_targets \{(.*?)\} dan_train_targets;", text, flags=re.S).group(1)
+    assert re.findall(r"\*\s*([a-z_]+)\s*;", body) == [f[0] for f in train._CTargets._fields_]
+
+
 def test_abi_version(lib):
     assert lib.dan_abi_version() == capi.ABI_VERSION
 

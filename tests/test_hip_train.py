@@ -1,0 +1,160 @@
+"""The HIP training step (through the C ABI of include/dl4vc_dan_train.h) against the fixtures the reference's own training
+loop produced (tests/golden/train_*.npz) and against the training oracle at production width.  GPU only."""
+import numpy as np
+import pytest
+
+from golden_util import load_train_case, train_cases
+from dl4vc_amd.config import DanConfig
+from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights
+from dl4vc_amd import synth
+from oracle.dan_oracle import random_state_dict
+from oracle import dan_train_oracle as T
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 1e-4          # every gradient tensor within 1e-4 of its max magnitude
+LOSS_TOL = 2e-5
+
+
+def cfg_from(spec) -> DanConfig:
+    keys = DanConfig.__dataclass_fields__.keys()
+    return DanConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in keys})
+
+
+def hyper_from(h) -> TrainHyper:
+    return TrainHyper(**{k: v for k, v in h.items() if k in TrainHyper.__dataclass_fields__})
+
+
+def check_grads(tr, want, tag, slack=None):
+    """``slack[k]``: extra relative allowance per tensor (the fp32 oracle's own distance from the float64 oracle where the
+    comparison is against the latter)."""
+    worst = ("", 0.0)
+    for k, g in want.items():
+        name = k
+        if k.startswith("conv2hidden."):
+            idx = sorted({int(q.split(".")[1]) for q in want if q.startswith("conv2hidden.")})
+            name = "fc.%d.%s" % (idx.index(int(k.split(".")[1])), k.split(".")[2])
+        got = tr.tensor("grad:" + name, g.shape)
+        scale = float(np.abs(g).max())
+        err = float(np.abs(got.astype(np.float64) - g).max())
+        if scale > 0 and err / scale > worst[1]:
+            worst = (k, err / scale)
+        tol = GRAD_RTOL + (2.0 * slack[k] if slack else 0.0)
+        assert err <= tol * scale + 1e-12, "%s: grad %s max abs err %.3g vs max |g| %.3g (tol %.2g)" % (tag, k, err, scale, tol)
+    return worst
+
+
+@pytest.mark.parametrize("case", train_cases())
+def test_train_step_matches_reference_training_loop(case):
+    spec, hyper, w, steps, final, adam, close = load_train_case(case)
+    cfg, hp = cfg_from(spec), hyper_from(hyper)
+    tr = DanTrainer(cfg, hp, max_batch=len(steps[0]["vcfrec"])).load_state_dict(w)
+    for s, st in enumerate(steps):
+        out = tr.train_step(st["planes"], st["targets"], dropout_masks=st["masks"] if hp.dropout > 0 else None)
+        for k in ("loss", "bin", "vt"):
+            assert abs(out[k] - float(st[k])) <= LOSS_TOL * max(1.0, abs(float(st[k]))), (case, s, k, out[k], float(st[k]))
+        assert np.array_equal(out["bin_close"], st["bin_close"]) and np.array_equal(out["vt_close"], st["vt_close"])
+        assert abs(out["grad_norm"] - float(st["grad_norm"])) <= 1e-4 * float(st["grad_norm"]), (out["grad_norm"], float(st["grad_norm"]))
+        worst = check_grads(tr, st["grad"], "%s step %d" % (case, s))
+        print("%s step %d: loss %.6f (ref %.6f), worst gradient %s at %.2g of its max" % (case, s, out["loss"], float(st["loss"]), *worst))
+    # state after the optimizer steps: parameters, BN running statistics, Adam moments
+    sd = tr.state_dict()
+    last = steps[-1]["grad"]
+    for k, ref in final.items():
+        if k == "pe":
+            continue
+        a, b = T.state_errors(sd[k], ref, last.get(k), hp.lr)
+        assert a < 1e-4 and b < 2.1 * len(steps), (case, k, a, b)
+    for k, ref in adam.items():
+        name = k.split(":", 1)[1]
+        if name.startswith("conv2hidden."):
+            idx = sorted({int(q.split(".")[1]) for q in final if q.startswith("conv2hidden.")})
+            name = "fc.%d.%s" % (idx.index(int(name.split(".")[1])), name.split(".")[2])
+        got = tr.tensor(("m:" if k.startswith("adam_m:") else "v:") + name, ref.shape)
+        assert np.abs(got - ref).max() <= 2e-4 * max(float(np.abs(ref).max()), 1e-30), (case, k)
+    assert tr.query("step") == len(steps)
+    tr.close()
+
+
+def test_train_forward_activations_match_oracle():
+    """Per-layer train-mode activations (BatchNorm on batch statistics) against the oracle's taps: localises a forward bug."""
+    spec, hyper, w, steps, *_ = load_train_case("train_small")
+    cfg, hp, st = cfg_from(spec), hyper_from(hyper), steps[0]
+    want = T.train_step_oracle(w, spec, st["planes"], st["targets"], T.TrainHyper(**hyper), dropout_masks=st["masks"], taps=True)
+    tr = DanTrainer(cfg, hp, max_batch=6).load_state_dict(w)
+    tr.backward(st["planes"], st["targets"], dropout_masks=st["masks"])
+    B, R, L = st["planes"][0].shape
+    for l in range(1, cfg.layers + 1):
+        x = tr.debug_buffer("act:x%d" % l, B * R * L * 128).reshape(B, R, L, 128)
+        ref = want["tap:conv%d" % l]                         # (B, C, R, L)
+        got = np.transpose(x[..., :ref.shape[1]], (0, 3, 1, 2))
+        err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        assert err < 1e-4, "layer %d output: rel err %.3g" % (l, err)
+        assert not np.any(x[..., ref.shape[1]:]), "pad channels of layer %d must stay zero" % l
+    F = tr.query("feature_width")
+    feat = tr.debug_buffer("feature", B * tr.query("feature_stride")).reshape(B, -1)[:, :F]
+    assert np.abs(feat - want["tap:feature"]).max() <= 1e-4 * max(1.0, np.abs(want["tap:feature"]).max())
+    logits = tr.debug_buffer("logits", B * 27).reshape(B, 27)
+    ref = np.concatenate([want["out:bin_logits"], want["out:vt_logits"]], axis=1)
+    assert np.abs(logits[:, :5] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    tr.close()
+
+
+def test_production_width_step_against_oracle():
+    """Full-width network (7 x 128 channels, bottleneck 32, all MFMA tiles live) on a small batch: every gradient against the
+    training oracle (which tests/test_train_oracle.py pins to the reference's loop) evaluated in FLOAT64.  At this width
+    fp32 itself is the limit: the fp32 oracle sits up to 2e-3 (of a tensor's max) from the float64 one on the smallest
+    gradients (a ReLU / max-pool decision flipping on a rounding error), so each tensor is allowed 1e-4 plus twice the fp32
+    oracle's own distance from float64 -- an fp32 implementation cannot be asked for more."""
+    cfg = DanConfig(reads=12, fc_sizes=(64, 32))
+    sd = random_state_dict(cfg, seed=17)
+    for k in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
+        sd[k + ".weight"] = (sd[k + ".weight"] * np.float32(0.05)).astype(np.float32)
+    B = 5
+    batch = synth.make_sites(B, reads=cfg.reads, seed=18)
+    rng = np.random.default_rng(19)
+    hp = TrainHyper()
+    tg = {"label": np.array([0, 2, 1, 0, 2]), "var_type": np.array([1, 0, 2, 2, 0]), "allele_freq": rng.random(B).astype(np.float32),
+          "coverage": rng.integers(5, 60, B).astype(np.float32), "var_base_enum": np.array([1, 2, 5, 8, 3]),
+          "var_ref_enum": np.array([4, 3, 1, 2, 2]), "is_snp": np.array([1, 1, 0, 0, 1], np.uint8)}
+    tg["weight"] = example_weights(tg["is_snp"], hp)
+    widths = (cfg.feature_width, 64, 32)
+    masks = [(rng.random((B, w)) >= hp.dropout).astype(np.uint8) for w in widths]
+    ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
+    import torch
+    want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64)
+    w32 = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks)
+    tr = DanTrainer(cfg, hp, max_batch=8).load_state_dict(sd)
+    out = tr.train_step(batch.arrays(), tg, dropout_masks=masks)
+    for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr"):
+        assert abs(out[k] - float(want[k])) <= 5e-5 * max(1.0, abs(float(want[k]))), (k, out[k], float(want[k]))
+    assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * float(want["grad_norm"])
+    grads = {k[5:]: v for k, v in want.items() if k.startswith("grad:")}
+    slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
+    worst = check_grads(tr, grads, "production width", slack)
+    print("production width: worst gradient %s at %.2g of its max" % worst)
+    tr.close()
+
+
+def test_device_dropout_masks_and_errors():
+    cfg = DanConfig(reads=6, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8))
+    sd = random_state_dict(cfg, seed=3)
+    batch = synth.make_sites(4, reads=6, seed=4)
+    tg = {"label": np.zeros(4), "var_type": np.ones(4), "allele_freq": np.full(4, 0.5), "coverage": np.full(4, 30.0),
+          "var_base_enum": np.ones(4), "var_ref_enum": np.full(4, 2), "weight": np.ones(4)}
+    runs = []
+    for seed in (7, 7, 8):
+        tr = DanTrainer(cfg, TrainHyper(dropout=0.5), max_batch=4).load_state_dict(sd)
+        runs.append(tr.train_step(batch.arrays(), tg, seed=seed)["loss"])
+        tr.close()
+    assert np.isfinite(runs).all() and runs[0] == runs[1] and runs[0] != runs[2]      # device masks: seeded, reproducible
+    tr = DanTrainer(cfg, TrainHyper(), max_batch=2).load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="1..2 sites"):
+        tr.train_step(batch.arrays(), tg)
+    tr.close()
+    bad = dict(sd)
+    del bad["bn1D_layers.2.running_var"]
+    with pytest.raises(RuntimeError, match="bn1D_layers.2"):
+        DanTrainer(cfg, TrainHyper(), max_batch=2).load_state_dict(bad)
+    with pytest.raises(RuntimeError, match="fp32"):
+        DanTrainer(DanConfig(reads=6, precision=2), TrainHyper(), max_batch=2)
