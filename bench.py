@@ -96,8 +96,122 @@ def parity_check(outs, want, period, precision):
     return res
 
 
+def bench_train(args):
+    """--mode train: BASELINE config 4's unit of work -- one optimisation step of the DAN network (train-mode forward with
+    BatchNorm batch statistics and dropout, loss mix, backward, gradient clipping, Adam; dl4vc/trainer.py:109-439) on a
+    synthetic batch of --train-batch sites x 100 reads x 201 bp per GPU (100 reads: the reference's dataset always yields
+    MAX_READS = 100, dl4vc/dataset.py:398), production network, fp32, seeded weights.  N > 1: one process per GPU, the flat
+    gradient buffer averaged with ONE RCCL all-reduce per step (replaces nn.DataParallel, main.py:117); weak scaling."""
+    import torch
+    from dl4vc_amd.config import DanConfig
+    from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights, average_gradients
+    from dl4vc_amd import synth
+    from dl4vc_amd.synth import random_state_dict
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the training step has no CPU path")
+    if os.environ.get("BENCH_FORCE_DEVICE0"):
+        local_rank = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    cfg = DanConfig(reads=100, length=args.window)
+    hp = TrainHyper()
+    B = args.train_batch
+    sd = random_state_dict(cfg, seed=0)
+    tr = DanTrainer(cfg, hp, max_batch=B, device_id=local_rank).load_state_dict(sd)
+    batch = synth.tile_sites(synth.make_sites(min(B, 64), reads=cfg.reads, length=cfg.length, seed=rank), B)
+    rng = np.random.default_rng(rank)
+    tg = {"label": rng.integers(0, 3, B), "var_type": rng.integers(0, 3, B), "allele_freq": rng.random(B).astype(np.float32),
+          "coverage": rng.integers(5, 90, B).astype(np.float32), "var_base_enum": rng.integers(1, 6, B),
+          "var_ref_enum": rng.integers(1, 5, B), "is_snp": rng.integers(0, 2, B)}
+    tg["weight"] = example_weights(tg["is_snp"], hp)
+    planes = batch.arrays()
+    grad = tr.grad_tensor() if world > 1 else None
+
+    def step(i):
+        out = tr.backward(planes, tg, seed=i)
+        if world > 1:
+            average_gradients(grad, world, dist.all_reduce)
+        tr.apply()
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        # algorithmic FLOPs of one step: every GEMM of the forward once more for its data gradient and once for its weight
+        # gradient (the layer-1 data gradient IS needed: the embeddings train)
+        flops_site = 3.0 * cfg.flops_per_site()
+        value = B * world * args.steps / elapsed
+        achieved = value / world * flops_site / 1e12
+        line = {"metric": "training sites/sec (DAN train step, 100 reads x %d bp)" % cfg.length, "value": round(value, 2),
+                "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "one optimisation step (train-mode forward, focal + aux losses, backward, clip, Adam) on %d sites "
+                                       "x 100 reads x %d bp per GPU, DAN production network, seeded random weights" % (B, cfg.length),
+                           "sites_per_gpu_per_step": B, "reads": 100, "window": cfg.length,
+                           "parallelism": "data-parallel x%d, one all-reduce of %d gradient floats per step" % (world, tr.query("num_param_floats")),
+                           "gflop_per_site": round(flops_site / 1e9, 3)},
+                "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                             "kernel": "whole step (train_row_kernel + train_wgrad_kernel dominate; profiles/r02_train_kernel_stats.csv)"},
+                "last_step": {k: round(float(last[k]), 6) for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.dan_train_oracle import train_step_oracle, TrainHyper as OH
+            cores = min(os.cpu_count() or 1, 16)
+            torch.set_num_threads(cores)
+            n = 2
+            masks = [np.ones((n, w), np.uint8) for w in (cfg.feature_width,) + tuple(cfg.fc_sizes)]
+            ohp = OH(**{k: getattr(hp, k) for k in OH.__dataclass_fields__})
+            sub = [a[:n] for a in planes]
+            stg = {k: v[:n] for k, v in tg.items()}
+            t1 = time.perf_counter()
+            train_step_oracle(sd, cfg, sub, stg, ohp, dropout_masks=masks)
+            dt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(n / dt, 3), "unit": "sites/s", "cores": int(cores), "kind": "port",
+                                    "sample": "one step of oracle/dan_train_oracle.py (torch CPU fp32 autograd) on %d sites x 100 reads x %d "
+                                              "bp; threads = min(host threads, 16)" % (n, cfg.length)}
+        if not all(np.isfinite(float(last[k])) for k in ("loss", "bin", "vt")):
+            print(json.dumps(line), flush=True)
+            raise SystemExit("bench.py --mode train: non-finite loss")
+        print(json.dumps(line), flush=True)
+    tr.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="infer", choices=("infer", "train"),
+                    help="infer (default, BASELINE.json's headline metric) or train (BASELINE config 4: one optimisation step)")
+    ap.add_argument("--train-batch", type=int, default=64, help="--mode train: sites per GPU per step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
@@ -119,6 +233,8 @@ def main():
                     help="compute the all-padding rows of each pileup once per site (bit-identical outputs; off for the headline, "
                          "which computes every row like the reference)")
     args = ap.parse_args()
+    if args.mode == "train":
+        return bench_train(args)
 
     import torch
     from dl4vc_amd.config import DanConfig

@@ -104,12 +104,13 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
                           int layer_stride_b, hipStream_t s);
 // embedding gradient with padding_idx 0 and scale_grad_by_freq (model.py:143-145) from dx0 rows [row][L][CPAD] (48 channels)
 void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
-                           float* g_emb, hipStream_t s);
+                           double* block_partial, float* g_emb, hipStream_t s);
 
 // ---- FC stack ------------------------------------------------------------------------------------------------------------------------
 // C[m][n] (+)= sum_k opA(m,k) * opB(n,k);  an operand is K-contiguous (X[i*ld + k]) or K-slow (X[k*ld + i])
+// split_ws: workspace for split-K partials (used when the tile grid cannot fill the chip and K is long), or nullptr
 void launch_gemm(const float* A, long long lda, int a_kslow, const float* B, long long ldb, int b_kslow, const float* bias,
-                 float* C, long long ldc, int M, int N, int K, int relu, hipStream_t s);
+                 float* C, long long ldc, int M, int N, int K, int relu, float* split_ws, long long split_ws_floats, hipStream_t s);
 // y[i] = x[i] * mask[i] * scale  (mask: one byte per element, row-major [rows][cols]; x, y with row stride ld)
 void launch_dropout(const float* x, const uint8_t* mask, float scale, float* y, int rows, int cols, long long ld, hipStream_t s);
 // dx = dy * mask * scale * (act > 0 || !relu)      (backward of Linear -> ReLU -> Dropout, act = the ReLU output)

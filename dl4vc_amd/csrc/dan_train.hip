@@ -13,6 +13,8 @@
 #include "dan_device.h"
 #include "dan_train.h"
 
+#include <algorithm>
+
 namespace dan {
 
 // ------------------------------------------------------------------------------------------------
@@ -634,6 +636,32 @@ __global__ __launch_bounds__(256) void highway_wgrad_kernel(const float* __restr
     }
 }
 
+// gbc[o] = sum over rows of dhw[row][o]: one block per split of the rows, fixed-order tree inside, splits summed by the reduce
+__global__ __launch_bounds__(256) void highway_bias_partial_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
+                                                                  int feat_off, float* __restrict__ bias_partial, int n_rows, int R, int H) {
+    __shared__ float red[8][HPAD];
+    const int tid = threadIdx.x, o = tid & 31, lane_row = tid >> 5;
+    const int per = (n_rows + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n_rows, lo + per);
+    float sum = 0.f;
+    if (o < H)
+        for (int row = lo + lane_row; row < hi; row += 8) sum += dhw_of(dfeat, feat, fs, feat_off, 0, H, R, row, o);
+    red[lane_row][o] = sum;
+    __syncthreads();
+    if (tid < HPAD) {
+        float t = 0.f;
+        for (int i = 0; i < 8; ++i) t += red[i][tid];
+        bias_partial[blockIdx.x * HPAD + tid] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void highway_bias_reduce_kernel(const float* __restrict__ bias_partial, int n_blocks, float* __restrict__ g_bc, int H) {
+    const int o = threadIdx.x;
+    if (o >= H) return;
+    float sum = 0.f;
+    for (int b = 0; b < n_blocks; ++b) sum += bias_partial[b * HPAD + o];
+    g_bc[o] = sum;
+}
+
 __global__ __launch_bounds__(256) void highway_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ g_wc, int L, int H) {
     const int idx = blockIdx.x * 256 + threadIdx.x;             // over (o, c, p) of the torch layout (H, H, 1, L)
     if (idx >= H * H * L) return;
@@ -642,15 +670,6 @@ __global__ __launch_bounds__(256) void highway_wgrad_reduce_kernel(const float* 
     float sum = 0.f;
     for (int sp = 0; sp < HW_SPLITS; ++sp) sum += partial[((size_t)sp * HPAD + o) * n_e + e];
     g_wc[idx] = sum;
-}
-
-__global__ __launch_bounds__(64) void highway_bias_grad_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
-                                                               int feat_off, float* __restrict__ g_bc, long long bc_layer, int n_rows, int R, int H) {
-    const int layer = blockIdx.x, o = threadIdx.x;
-    if (o >= H) return;
-    float sum = 0.f;
-    for (int row = 0; row < n_rows; ++row) sum += dhw_of(dfeat, feat, fs, feat_off, layer, H, R, row, o);
-    g_bc[(size_t)layer * bc_layer + o] = sum;
 }
 
 void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, int feat_off, const float* h, long long h_layer,
@@ -662,8 +681,12 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
                            h + (size_t)l * h_layer, partial, n_rows, R, L, H);
         hipLaunchKernelGGL(highway_wgrad_reduce_kernel, dim3((H * H * L + 255) / 256), dim3(256), 0, s, partial, g_wc + (size_t)l * wc_layer, L, H);
     }
-    hipLaunchKernelGGL(highway_bias_grad_kernel, dim3(layers), dim3(64), 0, s, dfeat, feat, fs, feat_off, g_bc, (long long)layer_stride_b,
-                       n_rows, R, H);
+    // (one layer per call: the compression layers' gradient tensors are not contiguous in the flat buffer)
+    constexpr int BIAS_BLOCKS = 64;
+    float* bias_partial = partial + (size_t)HW_SPLITS * HPAD * n_e;
+    hipLaunchKernelGGL(highway_bias_partial_kernel, dim3(BIAS_BLOCKS), dim3(256), 0, s, dfeat, feat, fs, feat_off, bias_partial, n_rows, R, H);
+    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3(1), dim3(64), 0, s, bias_partial, BIAS_BLOCKS, g_bc, H);
+    (void)layer_stride_b;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,12 +712,22 @@ __global__ __launch_bounds__(512) void embedding_partial_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(512) void embedding_reduce_kernel(const float* __restrict__ partial, int n_rows, float* __restrict__ g_emb) {
+constexpr int EMB_ROWS_PER_BLOCK = 64;
+__global__ __launch_bounds__(512) void embedding_block_kernel(const float* __restrict__ partial, int n_rows, double* __restrict__ bp) {
+    const int tid = threadIdx.x;
+    if (tid >= VOCAB * EMB_W) return;
+    const int lo = blockIdx.x * EMB_ROWS_PER_BLOCK, hi = min(n_rows, lo + EMB_ROWS_PER_BLOCK);
+    double sum = 0.0;
+    for (int r = lo; r < hi; ++r) sum += (double)partial[(size_t)r * VOCAB * EMB_W + tid];
+    bp[(size_t)blockIdx.x * VOCAB * EMB_W + tid] = sum;
+}
+
+__global__ __launch_bounds__(512) void embedding_reduce_kernel(const double* __restrict__ bp, int n_blocks, float* __restrict__ g_emb) {
     __shared__ double tot[VOCAB * EMB_W];
     const int tid = threadIdx.x;
     if (tid < VOCAB * EMB_W) {
         double sum = 0.0;
-        for (int r = 0; r < n_rows; ++r) sum += (double)partial[(size_t)r * VOCAB * EMB_W + tid];
+        for (int b = 0; b < n_blocks; ++b) sum += bp[(size_t)b * VOCAB * EMB_W + tid];
         tot[tid] = sum;
     }
     __syncthreads();
@@ -711,10 +744,11 @@ __global__ __launch_bounds__(512) void embedding_reduce_kernel(const float* __re
 }
 
 void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
-                           float* g_emb, hipStream_t s) {
-    const int n_rows = n_sites * R;
+                           double* block_partial, float* g_emb, hipStream_t s) {
+    const int n_rows = n_sites * R, nb = (n_rows + EMB_ROWS_PER_BLOCK - 1) / EMB_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(embedding_partial_kernel, dim3(n_rows), dim3(512), 0, s, dx0, reads, ref, R, L, partial);
-    hipLaunchKernelGGL(embedding_reduce_kernel, dim3(1), dim3(512), 0, s, partial, n_rows, g_emb);
+    hipLaunchKernelGGL(embedding_block_kernel, dim3(nb), dim3(512), 0, s, partial, n_rows, block_partial);
+    hipLaunchKernelGGL(embedding_reduce_kernel, dim3(1), dim3(512), 0, s, block_partial, nb, g_emb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,7 +761,7 @@ constexpr int GM = 128, GN = 128, GK = 32, GS_KC = GK + 8, GS_KS = GM + 4;
 template <bool A_KSLOW, bool B_KSLOW>
 __global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
                                                    const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N,
-                                                   int K, int relu, int tiles_n) {
+                                                   int K, int relu, int tiles_n, int k_per_split, float* __restrict__ split_out) {
     constexpr int SZA = A_KSLOW ? GK * GS_KS : GM * GS_KC, SZB = B_KSLOW ? GK * GS_KS : GN * GS_KC;
     __shared__ __attribute__((aligned(16))) float sa[2][SZA], sb[2][SZB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -769,13 +803,18 @@ __global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = splat(0.f);
-    const int KT = (K + GK - 1) / GK;
-    gload(0);
+    // split-K: blockIdx.y owns k in [k_lo, k_hi); its partial tile goes to split_out[split][M][N] (summed by
+    // gemm_split_reduce_kernel in split order, then bias / ReLU)
+    const int k_lo = blockIdx.y * k_per_split, k_hi = min(K, k_lo + k_per_split);
+    const int KT = (k_hi - k_lo + GK - 1) / GK;
+    const int Kfull = K;
+    K = k_hi;
+    gload(k_lo);
     sstore(0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) gload((kt + 1) * GK);
+        if (kt + 1 < KT) gload(k_lo + (kt + 1) * GK);
 #pragma unroll
         for (int g = 0; g < GK / 16; ++g) {
             v4f a[4], w[2];
@@ -807,11 +846,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, 
         if (kt + 1 < KT) sstore(cur ^ 1);
         __syncthreads();
     }
+    (void)Kfull;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = bn + wn + j * 16 + r16;
         if (n >= N) continue;
-        const float b = bias ? bias[n] : 0.f;
+        const float b = (bias && !split_out) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -819,6 +859,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, 
                 const int m = bm + wm + i * 16 + kk * 4 + jj;
                 if (m < M) {
                     float v = acc[i][j][jj] + b;
+                    if (split_out) { split_out[((size_t)blockIdx.y * M + m) * N + n] = v; continue; }
                     if (relu) v = fmaxf(v, 0.f);
                     C[(size_t)m * ldc + n] = v;
                 }
@@ -826,14 +867,40 @@ __global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, 
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ split_out, int splits, const float* __restrict__ bias,
+                                                                float* __restrict__ C, long long ldc, int M, int N, int relu) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N) return;
+    const int m = idx / N, n = idx % N;
+    float v = 0.f;
+    for (int sp = 0; sp < splits; ++sp) v += split_out[((size_t)sp * M + m) * N + n];
+    if (bias) v += bias[n];
+    if (relu) v = fmaxf(v, 0.f);
+    C[(size_t)m * ldc + n] = v;
+}
+
 void launch_gemm(const float* A, long long lda, int a_kslow, const float* B, long long ldb, int b_kslow, const float* bias,
-                 float* C, long long ldc, int M, int N, int K, int relu, hipStream_t s) {
-    const int tiles_m = (M + GM - 1) / GM, tiles_n = (N + GN - 1) / GN;
-    const dim3 grid((unsigned)(tiles_m * tiles_n)), blk(512);
-    if (!a_kslow && !b_kslow) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
-    else if (!a_kslow && b_kslow) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
-    else if (a_kslow && !b_kslow) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n);
+                 float* C, long long ldc, int M, int N, int K, int relu, float* split_ws, long long split_ws_floats, hipStream_t s) {
+    const int tiles_m = (M + GM - 1) / GM, tiles_n = (N + GN - 1) / GN, tiles = tiles_m * tiles_n;
+    // too few tiles to fill 256 CUs and a long K: split K (deterministic: partials summed in split order)
+    int splits = 1;
+    if (split_ws && tiles < 64 && K >= 64 * GK) {
+        splits = std::min(256 / tiles, K / (8 * GK));
+        while (splits > 1 && (long long)splits * M * N > split_ws_floats) --splits;
+    }
+    int k_per = K;
+    if (splits > 1) {
+        k_per = ((K + splits - 1) / splits + GK - 1) / GK * GK;
+        splits = (K + k_per - 1) / k_per;
+    }
+    float* so = splits > 1 ? split_ws : nullptr;
+    const dim3 grid((unsigned)tiles, (unsigned)splits), blk(512);
+    if (!a_kslow && !b_kslow) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n, k_per, so);
+    else if (!a_kslow && b_kslow) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n, k_per, so);
+    else if (a_kslow && !b_kslow) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n, k_per, so);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, blk, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, relu, tiles_n, k_per, so);
+    if (splits > 1)
+        hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, so, splits, bias, C, ldc, M, N, relu);
 }
 
 // ------------------------------------------------------------------------------------------------

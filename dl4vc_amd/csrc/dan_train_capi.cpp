@@ -90,6 +90,9 @@ struct dan_trainer {
     float *d_du = nullptr, *d_g[2] = {nullptr, nullptr}, *d_dn = nullptr, *d_dpool = nullptr, *d_dh = nullptr;
     float *d_partial = nullptr, *d_bias_partial = nullptr, *d_hw_partial = nullptr, *d_emb_partial = nullptr;
     float* d_clip = nullptr;
+    float* d_split_ws = nullptr;                               // split-K partials of the forward FC GEMMs
+    long long split_ws_floats = 0;
+    double* d_emb_bp = nullptr;
     int last_B = 0;
 };
 
@@ -353,8 +356,11 @@ int dan_train_finalize(dan_trainer_t* t) {
     if ((rc = talloc(t, &t->d_du, rows * rowf, false)) || (rc = talloc(t, &t->d_g[0], rows * rowf, false)) || (rc = talloc(t, &t->d_g[1], rows * rowf, false)) ||
         (rc = talloc(t, &t->d_dn, rows * rowf, false)) || (rc = talloc(t, &t->d_dpool, (size_t)B * rowf, false))) return rc;
     if ((rc = talloc(t, &t->d_partial, (size_t)TRAIN_PARTIAL_WGS * 3 * CPAD * CPAD, false)) || (rc = talloc(t, &t->d_bias_partial, (size_t)TRAIN_PARTIAL_WGS * CPAD, false)) ||
-        (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD, false)) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
+        (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD + 64 * HPAD, false)) ||
+        (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
         (rc = talloc(t, &t->d_clip, 4))) return rc;
+    t->split_ws_floats = (long long)32 * B * std::max(t->n0, t->n1);
+    if ((rc = talloc(t, &t->d_split_ws, (size_t)t->split_ws_floats, false))) return rc;
     HIPT(t, hipDeviceSynchronize());
     t->finalized = true;
     return DAN_OK;
@@ -502,9 +508,9 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
         launch_highway(t->d_h, h_layer, t->d_wc_pk, (long long)L * 2 * 2 * 256, t->d_bc_pad, t->d_feat, t->F_stride, 2 * c.c_final * L, B, R, L, H, NL, nullptr, s);
     // FC stack: Dropout -> Linear -> ReLU -> Dropout -> Linear -> ReLU -> Dropout (model.py:369-377)
     launch_dropout(t->d_feat, mk[0], dscale, t->d_featd, B, t->F, t->F_stride, s);
-    launch_gemm(t->d_featd, t->F_stride, 0, pp(t, t->p_fc0w), t->F_stride, 0, pp(t, t->p_fc0b), t->d_hid0, t->n0_stride, B, t->n0, (int)t->F_stride, 1, s);
+    launch_gemm(t->d_featd, t->F_stride, 0, pp(t, t->p_fc0w), t->F_stride, 0, pp(t, t->p_fc0b), t->d_hid0, t->n0_stride, B, t->n0, (int)t->F_stride, 1, t->d_split_ws, t->split_ws_floats, s);
     launch_dropout(t->d_hid0, mk[1], dscale, t->d_hid0d, B, t->n0, t->n0_stride, s);
-    launch_gemm(t->d_hid0d, t->n0_stride, 0, pp(t, t->p_fc1w), t->n0_stride, 0, pp(t, t->p_fc1b), t->d_hid1, t->n1_stride, B, t->n1, (int)t->n0_stride, 1, s);
+    launch_gemm(t->d_hid0d, t->n0_stride, 0, pp(t, t->p_fc1w), t->n0_stride, 0, pp(t, t->p_fc1b), t->d_hid1, t->n1_stride, B, t->n1, (int)t->n0_stride, 1, t->d_split_ws, t->split_ws_floats, s);
     launch_dropout(t->d_hid1, mk[2], dscale, t->d_hid1d, B, t->n1, t->n1_stride, s);
     {
         LossArgs a{};
@@ -523,14 +529,14 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
     launch_heads_bwd(t->d_dlogits, t->d_hid1d, pp(t, t->p_hw), B, t->n1, (int)t->n1_stride, t->d_dhid1d, gp(t, t->p_hw), gp(t, t->p_hb), s);
     launch_dropout_relu_bwd(t->d_dhid1d, mk[2], dscale, t->d_hid1, 1, t->d_dhid1, B, t->n1, t->n1_stride, s);
     // FC2: gW1[n][k] = sum_b d1[b][n] hid0d[b][k];  d(hid0d) = d1 W1
-    launch_gemm(t->d_dhid1, t->n1_stride, 1, t->d_hid0d, t->n0_stride, 1, nullptr, gp(t, t->p_fc1w), t->n0_stride, t->n1, t->n0, B, 0, s);
+    launch_gemm(t->d_dhid1, t->n1_stride, 1, t->d_hid0d, t->n0_stride, 1, nullptr, gp(t, t->p_fc1w), t->n0_stride, t->n1, t->n0, B, 0, t->d_split_ws, t->split_ws_floats, s);
     launch_colsum(t->d_dhid1, B, t->n1, t->n1_stride, gp(t, t->p_fc1b), s);
-    launch_gemm(t->d_dhid1, t->n1_stride, 0, pp(t, t->p_fc1w), t->n0_stride, 1, nullptr, t->d_dhid0d, t->n0_stride, B, t->n0, t->n1, 0, s);
+    launch_gemm(t->d_dhid1, t->n1_stride, 0, pp(t, t->p_fc1w), t->n0_stride, 1, nullptr, t->d_dhid0d, t->n0_stride, B, t->n0, t->n1, 0, t->d_split_ws, t->split_ws_floats, s);
     launch_dropout_relu_bwd(t->d_dhid0d, mk[1], dscale, t->d_hid0, 1, t->d_dhid0, B, t->n0, t->n0_stride, s);
     // FC1
-    launch_gemm(t->d_dhid0, t->n0_stride, 1, t->d_featd, t->F_stride, 1, nullptr, gp(t, t->p_fc0w), t->F_stride, t->n0, t->F, B, 0, s);
+    launch_gemm(t->d_dhid0, t->n0_stride, 1, t->d_featd, t->F_stride, 1, nullptr, gp(t, t->p_fc0w), t->F_stride, t->n0, t->F, B, 0, t->d_split_ws, t->split_ws_floats, s);
     launch_colsum(t->d_dhid0, B, t->n0, t->n0_stride, gp(t, t->p_fc0b), s);
-    launch_gemm(t->d_dhid0, t->n0_stride, 0, pp(t, t->p_fc0w), t->F_stride, 1, nullptr, t->d_dfeatd, t->F_stride, B, t->F, t->n0, 0, s);
+    launch_gemm(t->d_dhid0, t->n0_stride, 0, pp(t, t->p_fc0w), t->F_stride, 1, nullptr, t->d_dfeatd, t->F_stride, B, t->F, t->n0, 0, t->d_split_ws, t->split_ws_floats, s);
     launch_dropout_relu_bwd(t->d_dfeatd, mk[0], dscale, nullptr, 0, t->d_dfeat, B, t->F, t->F_stride, s);
     // highway compression
     const int hw_off = 2 * c.c_final * L;
@@ -626,7 +632,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
     {
         RowArgs e{};
         fill_encode(e, t, B);
-        launch_embedding_grad(t->d_du, e.reads, e.ref, B, R, L, t->d_emb_partial, gp(t, t->p_emb), s);
+        launch_embedding_grad(t->d_du, e.reads, e.ref, B, R, L, t->d_emb_partial, t->d_emb_bp, gp(t, t->p_emb), s);
     }
     HIPT(t, hipGetLastError());
     HIPT(t, hipDeviceSynchronize());
@@ -659,6 +665,13 @@ int dan_train_step(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qual, 
     int rc = dan_train_backward(t, reads, qual, strand, ref, ref_mask, var_mask, n_sites, targets, dropout_masks, seed, losses, close);
     if (rc) return rc;
     return dan_train_apply(t, grad_norm);
+}
+
+int dan_train_set_lr(dan_trainer_t* t, float lr) {
+    if (!t) return DAN_ERR_INVALID_ARG;
+    if (!(lr >= 0.f)) return failt(t, DAN_ERR_INVALID_ARG, "learning rate must be >= 0");
+    t->hp.lr = lr;
+    return DAN_OK;
 }
 
 void* dan_train_grad_buffer(dan_trainer_t* t, int64_t* n_floats) {

@@ -241,3 +241,55 @@ def random_state_dict(cfg, seed: int = 0, dropout_keys: bool = True) -> Dict[str
     sd["bin_output_weights"] = np.full((1,), 0.1, np.float32)
     sd["vt_output_weights"] = np.full((1,), 0.1, np.float32)
     return sd
+
+
+def torch_default_init(cfg, seed: int = 1, dropout_keys: bool = True) -> Dict[str, np.ndarray]:
+    """A fresh model's state in the reference's key names, drawn from the distributions torch's constructors use for the
+    reference's modules (nn.Conv2d / nn.Linear: kaiming_uniform(a=sqrt 5) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight
+    and bias; nn.Embedding: N(0, 1) with the padding row zeroed; BatchNorm: weight 1, bias 0, running mean 0 / var 1;
+    dl4vc/model.py:143-145,211-262,362-377,406-415).  The VALUES differ from a reference run with the same --seed (torch's
+    generator and construction order are not reproduced): training from scratch starts from an equivalent, not identical,
+    point.  Resume from a checkpoint (--modelload) for an identical one."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+
+    def uni(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return rng.uniform(-b, b, shape).astype(np.float32)
+
+    emb = rng.standard_normal((V.VOCAB_SIZE, cfg.embed_dim)).astype(np.float32)
+    emb[0] = 0.0
+    sd["embeddings.weight"] = emb
+    sd["pe"] = sinusoid_pe(cfg.length, cfg.embed_dim)
+    for l in range(1, cfg.layers + 1):
+        cin, cout, _ = cfg.layer_dims(l)
+        sd["conv1D_layers.%d.weight" % (l - 1)] = uni((cout, cin, 1, 3), cin * 3)
+        sd["conv1D_layers.%d.bias" % (l - 1)] = uni((cout,), cin * 3)
+        p = "bn1D_layers.%d." % (l - 1)
+        sd[p + "weight"] = np.ones(cout, np.float32)
+        sd[p + "bias"] = np.zeros(cout, np.float32)
+        sd[p + "running_mean"] = np.zeros(cout, np.float32)
+        sd[p + "running_var"] = np.ones(cout, np.float32)
+        if cfg.is_residual(l):
+            i = l - cfg.residual_start
+            sd["residual_conv_layers.%d.weight" % i] = uni((cout, cout, 1, 1), cout)
+            sd["residual_conv_layers.%d.bias" % i] = uni((cout,), cout)
+        if cfg.bottleneck > 0:
+            H = cfg.bottleneck
+            sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)] = uni((H, cout, 1, 1), cout)
+            sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)] = uni((H,), cout)
+            sd["conv1D_compression_layers.%d.weight" % (l - 1)] = uni((H, H, 1, cfg.length), H * cfg.length)
+            sd["conv1D_compression_layers.%d.bias" % (l - 1)] = uni((H,), H * cfg.length)
+    sizes = [cfg.feature_width] + list(cfg.fc_sizes)
+    for i in range(len(sizes) - 1):
+        k = "conv2hidden.%d" % ((1 + 3 * i) if dropout_keys else 3 * i)
+        sd[k + ".weight"] = uni((sizes[i + 1], sizes[i]), sizes[i])
+        sd[k + ".bias"] = uni((sizes[i + 1],), sizes[i])
+    hid = sizes[-1]
+    for name, n in (("fcHidden2BinTarget", 2), ("fcHidden2VT", 3), ("fcHidden2AF", 1), ("fcHidden2Coverage", 1),
+                    ("fcHidden2VB", V.VOCAB_SIZE), ("fcHidden2VR", V.VOCAB_SIZE)):
+        sd[name + ".weight"] = uni((n, hid), hid)
+        sd[name + ".bias"] = uni((n,), hid)
+    sd["bin_output_weights"] = np.full((1,), 0.1, np.float32)
+    sd["vt_output_weights"] = np.full((1,), 0.1, np.float32)
+    return sd

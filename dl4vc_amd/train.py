@@ -21,7 +21,7 @@ from .config import DanConfig
 from .model import normalise_state_dict
 
 TRAIN_SYMBOLS = ("dan_train_create", "dan_train_set_tensor", "dan_train_finalize", "dan_train_destroy", "dan_train_last_error",
-                 "dan_train_backward", "dan_train_apply", "dan_train_step", "dan_train_grad_buffer", "dan_train_get_tensor",
+                 "dan_train_backward", "dan_train_apply", "dan_train_step", "dan_train_set_lr", "dan_train_grad_buffer", "dan_train_get_tensor",
                  "dan_train_put_tensor", "dan_train_query")
 
 LOSS_NAMES = ("loss", "bin", "vt", "af", "cov", "vb", "vr")
@@ -83,6 +83,7 @@ def _bind(lib):
     lib.dan_train_backward.argtypes = [vp] + planes + [C.c_int64, C.POINTER(_CTargets), C.POINTER(vp), C.c_uint64, vp, vp]
     lib.dan_train_apply.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dan_train_step.argtypes = [vp] + planes + [C.c_int64, C.POINTER(_CTargets), C.POINTER(vp), C.c_uint64, vp, vp, C.POINTER(C.c_float)]
+    lib.dan_train_set_lr.argtypes = [vp, C.c_float]
     lib.dan_train_grad_buffer.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.dan_train_grad_buffer.restype = vp
     lib.dan_train_get_tensor.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
@@ -234,6 +235,12 @@ class DanTrainer:
 
     def train_step(self, planes: Sequence, targets: Mapping, dropout_masks=None, seed: int = 0) -> Dict[str, object]:
         return self._call(self.lib.dan_train_step, planes, targets, dropout_masks, seed, True)
+
+    def set_lr(self, lr: float) -> None:
+        """``optimizer.param_groups[0]['lr'] *= args.lr_decay`` (main.py:166)."""
+        import dataclasses
+        self._check(self.lib.dan_train_set_lr(self._h, float(lr)), "dan_train_set_lr")
+        self.hyper = dataclasses.replace(self.hyper, lr=float(lr))
 
     # ---- state --------------------------------------------------------------------------------------------------
     def query(self, what: str) -> int:

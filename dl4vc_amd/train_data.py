@@ -1,0 +1,138 @@
+"""Training-side batch assembly and example sampling (the training slice of row A2).
+
+Restates what the reference's dataset adds for training on top of the six input planes
+(``ContextDatasetFromNumpy._get_generator``, dl4vc/dataset.py:583-680) and its epoch sampler
+(``AdjustableDataSampler``, dl4vc/dataset.py:683-749):
+
+* targets per site: ``label`` (the record's field: 0 TP, 1 FN, 2 FP), ``var_type`` / ``is_snp`` / ``var_base_enum`` /
+  ``var_ref_enum`` from the VCF line (``utils.parse_vcf``, utils.py:19-72 -- the truth genotype is the optional 11th
+  column ``GT:a/b``), ``coverage`` = reads covering the centre column counted from the SELECTED reads when that count is
+  positive, else the VCF's DP (dataset.py:603-620), ``allele_freq`` = the candidate's AF (``--aux-keep-candidate-af``, the
+  published flag) or the counted variant fraction;
+* the example weight ``(is_snp + (1 - is_snp) * non_snp_train_weight)`` (trainer.py:169-172);
+* the easy-example sampler: every epoch keeps all examples that are neither "close" (well classified, trainer.py:258-264),
+  black-listed nor held out, plus a random ``close_examples_sample_rate`` share of the close ones, in shuffled order.
+
+Not restated (off in the published scripts, rejected by the CLI when requested): read / reference noise augmentation
+(dataset.py:17-80,292-336), dynamic read down-sampling (dataset.py:258-262).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .alleles import parse_candidate, count_center_support
+from .dataset import assemble_site
+from .synth import SiteBatch
+
+TARGET_KEYS = ("label", "var_type", "allele_freq", "coverage", "var_base_enum", "var_ref_enum", "is_snp", "weight")
+
+
+@dataclass
+class TrainBatch:
+    sites: SiteBatch
+    targets: Dict[str, np.ndarray]
+    index: np.ndarray              # absolute record indices (the loop writes close flags back by index, trainer.py:263)
+    blacklist: np.ndarray
+    names: List[str]
+
+    def planes(self):
+        return self.sites.arrays()
+
+    def __len__(self):
+        return len(self.index)
+
+
+def site_targets(record, site, keep_candidate_af: bool = True) -> Dict[str, float]:
+    """dataset.py:584-620 for one assembled site."""
+    info = parse_candidate(site.vcfrec)
+    coverage = info["coverage"]
+    allele_freq = info["allele_freq"]
+    cover, _agree, variant = count_center_support(np.ascontiguousarray(site.reads.T), site.ref, info["var_mode"])
+    if cover > 0:                                               # dataset.py:614-620
+        coverage = cover
+        if not keep_candidate_af:
+            allele_freq = variant / cover
+    return {"label": int(np.asarray(record["label"]).reshape(-1)[0]), "var_type": int(info["var_type"]),
+            "allele_freq": float(allele_freq), "coverage": float(coverage), "var_base_enum": int(info["var_base"]),
+            "var_ref_enum": int(info["ref_base"]), "is_snp": int(bool(info["is_snp"]))}
+
+
+def assemble_training_batch(records, indices: Sequence[int], max_reads: int, seed: Optional[int] = None,
+                            non_snp_train_weight: float = 1.0, keep_candidate_af: bool = True, use_q: bool = True,
+                            use_strand: bool = True, trust_weight=None) -> TrainBatch:
+    """``records[i]`` is the structured record of absolute index ``indices[i]``.  ``seed`` pins the read subset of deep
+    pileups as in ``dataset.assemble_batch`` (RandomState(seed + absolute index))."""
+    sites, tgs = [], []
+    for rec, idx in zip(records, indices):
+        rng = np.random.RandomState(seed + int(idx)) if seed is not None else None
+        site = assemble_site(rec, max_reads, rng, use_q=use_q, use_strand=use_strand)
+        sites.append(site)
+        tgs.append(site_targets(rec, site, keep_candidate_af))
+    stack = lambda f: np.stack([getattr(s, f) for s in sites])   # noqa: E731
+    batch = SiteBatch(stack("reads"), stack("qual"), stack("strand"), stack("ref"), stack("ref_mask"), stack("var_mask"),
+                      [s.vcfrec for s in sites], np.array([s.num_reads for s in sites], np.int32))
+    t = {"label": np.array([g["label"] for g in tgs], np.uint8), "var_type": np.array([g["var_type"] for g in tgs], np.uint8),
+         "allele_freq": np.array([g["allele_freq"] for g in tgs], np.float32),
+         "coverage": np.array([g["coverage"] for g in tgs], np.float32),
+         "var_base_enum": np.array([g["var_base_enum"] for g in tgs], np.uint8),
+         "var_ref_enum": np.array([g["var_ref_enum"] for g in tgs], np.uint8),
+         "is_snp": np.array([g["is_snp"] for g in tgs], np.uint8)}
+    s = t["is_snp"].astype(np.float32)
+    w = s + (1.0 - s) * np.float32(non_snp_train_weight)         # trainer.py:169-172
+    if trust_weight is not None:
+        w = w * np.asarray(trust_weight, np.float32)
+    t["weight"] = w.astype(np.float32)
+    return TrainBatch(batch, t, np.asarray(indices, np.int64), np.array([s.blacklist for s in sites], bool),
+                      [s.name for s in sites])
+
+
+class EasyExampleSampler:
+    """``AdjustableDataSampler`` (dl4vc/dataset.py:683-749, built at main.py:72-74 when ``close_examples_sample_rate < 1``).
+
+    Holds the per-example tables the training loop updates (``close``: trainer.py:263-264 via ``update_close_example``;
+    ``blacklist``: trainer.py:267) and yields one epoch's index order.  ``rng`` is a ``np.random.RandomState``: the reference
+    draws from numpy's global legacy generator, so ``RandomState(s)`` here reproduces ``np.random.seed(s)`` there draw for
+    draw (one ``permutation`` of the close indices, one ``permutation`` of the merged list)."""
+
+    def __init__(self, n_examples: int, close_keep: float = 0.15, holdout: Optional[np.ndarray] = None,
+                 reverse_holdout: bool = False, shuffle: bool = True, rng: Optional[np.random.RandomState] = None):
+        self.n = int(n_examples)
+        self.close_keep = float(close_keep)
+        self.close = np.zeros(self.n, bool)
+        self.blacklist = np.zeros(self.n, bool)
+        self.holdout = np.zeros(self.n, bool) if holdout is None else np.asarray(holdout, bool)
+        self.reverse_holdout, self.shuffle = reverse_holdout, shuffle
+        self.rng = rng if rng is not None else np.random.RandomState()
+        self.epochs = 0
+        self.epoch_len = self.n
+
+    def update_close(self, indices, flags) -> None:               # trainer.py:25-40
+        self.close[np.asarray(indices, np.int64)] = np.asarray(flags, bool)
+
+    def update_blacklist(self, indices, flags) -> None:           # trainer.py:52-59: only ever sets
+        idx = np.asarray(indices, np.int64)[np.asarray(flags, bool)]
+        self.blacklist[idx] = True
+
+    def epoch(self) -> np.ndarray:
+        self.epochs += 1
+        if self.reverse_holdout:                                  # dataset.py:706-711: evaluation on the held-out chromosomes only
+            order = np.nonzero(~self.close & ~self.blacklist & self.holdout)[0]
+        else:
+            keep = np.nonzero(~self.close & ~self.blacklist & ~self.holdout)[0]
+            n_close = int(self.close.sum())
+            n_take = int(self.close_keep * n_close)               # dataset.py:720
+            # dataset.py:727-729, quirk included: with no close example `[-0:]` is the WHOLE index array, so the reference
+            # permutes all n indices (and keeps none) -- the draw is reproduced so the next shuffle sees the same state
+            close_idx = np.argsort(self.close)[-n_close:]
+            take = self.rng.permutation(close_idx)[:n_take]
+            order = np.concatenate((keep, take)).astype(np.int64)
+        self.epoch_len = len(order)
+        if self.shuffle:
+            return self.rng.permutation(order)                    # dataset.py:744
+        return order
+
+    def __len__(self):
+        return self.epoch_len

@@ -1,0 +1,188 @@
+"""Training harness: the epoch loop around the HIP training step.
+
+Stands where ``dl4vc/trainer.py::train`` (trainer.py:64-472) and the epoch loop of ``main.py`` (main.py:151-199) stand:
+iterate the sampler's order in batches, assemble planes + targets, one ``DanTrainer.train_step`` per batch, write the
+close-example / blacklist flags back into the sampler (trainer.py:258-267), print the reference's progress line
+(trainer.py:443-448); after an epoch decay the learning rate (main.py:166), evaluate on the test file (the same loss mix in
+eval mode, trainer.py:575-604, and the scored VCF, trainer.py:678-681) and save ``<name>_epoch<N><ext>`` / ``<name>_best<ext>``
+checkpoints (utils.py:180-186) holding ``{'epoch','state_dict','best_loss','optimizer'}`` with ``module.``-prefixed keys as
+the reference's DataParallel wrapper produces (main.py:194-199).
+
+Data parallelism: one process per GPU; the ``--batch-size`` sites of a step are split over the ranks the way
+``nn.DataParallel`` scatters them (main.py:117), every rank runs forward + backward on its share (BatchNorm statistics per
+replica, as DataParallel does), the flat gradient buffers are averaged with ONE all-reduce (RCCL over xGMI) and every rank
+applies the same Adam update.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+from .hdf5io import CandidateFile
+from .train_data import assemble_training_batch, EasyExampleSampler
+from .train import TrainHyper, average_gradients
+
+COVERAGE_SCALE_FACTOR = 1.0 / 100.0                       # trainer.py:61
+BASE_CLASS_WEIGHT = np.array([0.001, 1., 1., 1., 1., 1., 0.001, 0.001, 1., 0.001])     # trainer.py:312-313
+
+
+# ------------------------------------------------------------------------------------------------
+# the loss mix on host arrays (evaluation only: trainer.py:575-604 runs the same criteria under no_grad)
+# ------------------------------------------------------------------------------------------------
+def _softmax(x):
+    e = np.exp(x - x.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def _focal(logits, target, weight, pos_weight, hp: TrainHyper):
+    """objectives.py:77-112 (logits=True), float64."""
+    x = np.asarray(logits, np.float64)
+    n = x.shape[1]
+    y = np.full_like(x, hp.label_smoothing / (n - 1))
+    y[np.arange(len(x)), target] = 1.0 - hp.label_smoothing
+    ce = weight[:, None] * (np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x))))
+    p = np.clip(_softmax(x), 0.0, 1.0)
+    pt = y * p + (1 - y) * (1 - p)
+    w = (1 - pt) ** hp.focal_gamma * (pos_weight / pos_weight.sum())
+    return float((hp.focal_alpha * w * ce).sum(axis=1).mean())
+
+
+def eval_losses(out: Dict[str, np.ndarray], targets: Dict[str, np.ndarray], hp: TrainHyper) -> Dict[str, float]:
+    """``out``: bin_logits, vt_logits, af, cov, vb, vr of an eval-mode forward (``DanNet.forward_u8(aux=True)``)."""
+    w = np.asarray(targets["weight"], np.float64)
+    t_bin = (np.asarray(targets["label"]) <= 1).astype(np.int64)                        # trainer.py:134
+    t_vt = np.asarray(targets["var_type"]).astype(np.int64)
+    bin_loss = _focal(out["bin_logits"], t_bin, w, np.array([hp.fp_train_weight, 1.0]), hp)
+    vt_loss = _focal(out["vt_logits"], t_vt, w, np.array([hp.fp_train_weight, 1.0, 1.0]), hp)
+    af = np.asarray(out["af"], np.float64).reshape(-1)
+    t_af = np.asarray(targets["allele_freq"], np.float64)
+    af_loss = float((-w * (t_af * np.maximum(np.log(af), -100) + (1 - t_af) * np.maximum(np.log1p(-af), -100))).mean())
+    cov = np.asarray(out["cov"], np.float64).reshape(-1)
+    cov_loss = float(((cov - np.asarray(targets["coverage"], np.float64) * COVERAGE_SCALE_FACTOR) ** 2).mean())
+
+    def ce(logits, y):
+        x = np.asarray(logits, np.float64)
+        lse = np.log(np.exp(x - x.max(axis=1, keepdims=True)).sum(axis=1)) + x.max(axis=1)
+        wy = BASE_CLASS_WEIGHT[y]
+        return float((wy * (lse - x[np.arange(len(x)), y])).sum() / wy.sum())
+
+    vb_loss = ce(out["vb"], np.asarray(targets["var_base_enum"]).astype(np.int64))
+    vr_loss = ce(out["vr"], np.asarray(targets["var_ref_enum"]).astype(np.int64))
+    loss = bin_loss * hp.binary_weight + (vt_loss + af_loss * hp.aux_allele_weight + cov_loss +
+                                          (vb_loss + vr_loss) * hp.aux_bases_weight) * hp.aux_weight   # trainer.py:426-427
+    return {"loss": loss, "bin": bin_loss, "vt": vt_loss, "af": af_loss, "cov": cov_loss, "vb": vb_loss, "vr": vr_loss}
+
+
+# ------------------------------------------------------------------------------------------------
+def read_indices(source: CandidateFile, indices: np.ndarray) -> np.ndarray:
+    """Records at arbitrary (shuffled) indices: sorted, read in runs of consecutive indices, returned in request order."""
+    indices = np.asarray(indices, np.int64)
+    order = np.argsort(indices, kind="stable")
+    srt = indices[order]
+    out = np.empty(len(indices), dtype=source.dtype)
+    i = 0
+    while i < len(srt):
+        j = i
+        while j + 1 < len(srt) and srt[j + 1] - srt[j] <= 1:
+            j += 1
+        block = source.read(int(srt[i]), int(srt[j]) + 1)
+        out[order[i:j + 1]] = block[srt[i:j + 1] - srt[i]]
+        i = j + 1
+    return out
+
+
+def split_batch(n: int, rank: int, world: int):
+    """The slice of a batch of ``n`` sites that ``nn.DataParallel``'s scatter (torch.chunk along dim 0) gives replica ``rank``."""
+    chunk = -(-n // world)
+    lo = min(n, rank * chunk)
+    return lo, min(n, lo + chunk)
+
+
+def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyper: TrainHyper, batch_size: int, epoch: int,
+                reads_seed: int = 0, max_batches: int = 0, keep_candidate_af: bool = True, log: Optional[Callable] = print,
+                rank: int = 0, world: int = 1, all_reduce=None, gather=None, log_interval: int = 1) -> Dict[str, float]:
+    """One pass of ``trainer.train`` (trainer.py:64-472).  ``trainer``: anything with ``backward`` / ``apply`` (and
+    ``grad_tensor`` when ``world > 1``) -- ``DanTrainer`` on the GPU.  Returns the epoch's mean losses."""
+    order = sampler.epoch()
+    cfg = trainer.config
+    tot = {k: 0.0 for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}
+    n_batches = close_n = items = 0
+    t0 = time.perf_counter()
+    for b, lo in enumerate(range(0, len(order), batch_size)):
+        if max_batches > 0 and b > max_batches:                       # trainer.py:113-115 (same off-by-one)
+            break
+        idx = order[lo:lo + batch_size]
+        a, e = split_batch(len(idx), rank, world)
+        mine = idx[a:e]
+        if len(mine) == 0:
+            raise RuntimeError("batch of %d sites leaves rank %d of %d without work: lower --gpus or raise --batch-size" % (len(idx), rank, world))
+        batch = assemble_training_batch(read_indices(source, mine), mine, cfg.reads, seed=reads_seed,
+                                        non_snp_train_weight=hyper.non_snp_train_weight, keep_candidate_af=keep_candidate_af,
+                                        use_q=cfg.use_q, use_strand=cfg.use_strand)
+        out = trainer.backward(batch.planes(), batch.targets, seed=reads_seed + epoch)
+        if world > 1:
+            average_gradients(trainer.grad_tensor(), world, all_reduce)
+        trainer.apply()
+        flags = [(mine, out["vt_close"], batch.blacklist)]
+        if world > 1 and gather is not None:
+            flags = gather(flags[0])
+        for ids, close, black in flags:                                # trainer.py:263-267
+            sampler.update_close(ids, close)
+            sampler.update_blacklist(ids, black)
+            close_n += int(np.sum(close))
+            items += len(ids)
+        for k in tot:
+            tot[k] += out[k]
+        n_batches += 1
+        if log and rank == 0 and b % max(log_interval, 1) == 0:
+            n = n_batches
+            log("  Elapsed ({:.02e}s) [{}/{} ({:.0f}%)]  Loss: {:.6f}  Total: {:.6f}| bin: {:.5f} vt: {:.5f} dlt: {:.5f} af: {:.5f} cov: {:.5f} bases: {:.5f}".format(
+                time.perf_counter() - t0, b * batch_size, len(order), 100.0 * lo / max(len(order), 1), out["loss"], tot["loss"] / n,
+                tot["bin"] / n, tot["vt"] / n, 0.0, tot["af"] / n, tot["cov"] / n, (tot["vb"] + tot["vr"]) / n))
+            t0 = time.perf_counter()
+    if log and rank == 0:
+        log('%d/%d [%.2f%%] "close matches" within %.2f * %.5f (label smoothing) of true label' %
+            (close_n, items, close_n / max(items, 1) * 100.0, hyper.close_match_window, hyper.label_smoothing))
+    return {k: v / max(n_batches, 1) for k, v in tot.items()}
+
+
+def evaluate(net, source: CandidateFile, hyper: TrainHyper, batch_size: int, write: Optional[Callable[[str], None]] = None,
+             reads_seed: int = 0, max_batches: int = 0, indices: Optional[np.ndarray] = None) -> float:
+    """Eval-mode pass over the test file (trainer.py:509-681): mean over batches of the loss mix; optionally the scored VCF
+    records.  ``net``: a ``DanNet`` (running BatchNorm statistics, no dropout)."""
+    from .vcf import scored_record
+    cfg = net.config
+    idx_all = np.arange(len(source)) if indices is None else np.asarray(indices)
+    total, n_batches = 0.0, 0
+    for b, lo in enumerate(range(0, len(idx_all), batch_size)):
+        if max_batches > 0 and b > max_batches:                       # trainer.py:513-515
+            break
+        idx = idx_all[lo:lo + batch_size]
+        batch = assemble_training_batch(read_indices(source, idx), idx, cfg.reads, seed=reads_seed,
+                                        non_snp_train_weight=hyper.non_snp_train_weight, use_q=cfg.use_q, use_strand=cfg.use_strand)
+        out = net.forward_u8(*batch.planes(), aux=True)
+        total += eval_losses(out, batch.targets, hyper)["loss"]
+        n_batches += 1
+        if write:
+            write("".join(scored_record(r, bp, v) + "\n" for r, bp, v in zip(batch.sites.vcfrec, out["bp"], out["vt_prob"])))
+    return total / max(n_batches, 1)
+
+
+def save_checkpoint(state: dict, is_best: bool, filename: str = "checkpoint.pth.tar") -> None:
+    """utils.py:180-186."""
+    import torch
+    base, ext = os.path.splitext(filename)
+    torch.save(state, "{}_epoch{}{}".format(base, state["epoch"], ext))
+    if is_best:
+        torch.save(state, "{}_best{}".format(base, ext))
+
+
+def checkpoint_state(trainer, epoch: int, best_loss: float) -> dict:
+    """The dict the reference saves (main.py:194-199): DataParallel-prefixed state_dict + Adam state by parameter name."""
+    import torch
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in trainer.state_dict(prefix="module.").items()}
+    opt = {"step": trainer.query("step"), "lr": trainer.hyper.lr}
+    return {"epoch": epoch, "state_dict": sd, "best_loss": best_loss, "optimizer": opt}

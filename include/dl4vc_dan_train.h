@@ -82,6 +82,9 @@ int dan_train_step(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qual, 
                    const dan_train_targets* targets, const uint8_t* const* dropout_masks, uint64_t seed,
                    float* losses, uint8_t* close, float* grad_norm);
 
+/* Replaces  optimizer.param_groups[0]['lr'] *= args.lr_decay  (main.py:166). */
+int dan_train_set_lr(dan_trainer_t* t, float lr);
+
 /* Flat fp32 gradient buffer on the device (all parameters, fixed order) for the data-parallel average: ranks all-reduce
  * it (RCCL) between dan_train_backward and dan_train_apply.  Replaces nn.DataParallel's reduce-add (main.py:117). */
 void* dan_train_grad_buffer(dan_trainer_t* t, int64_t* n_floats);

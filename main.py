@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Drop-in for the inference-only mode of the reference's ``main.py`` (main.py:47-229, branch :213-222).
+"""Drop-in for the reference's ``main.py`` (main.py:47-229): inference-only mode (branch :213-222) and, with
+``--train_file``, training + per-epoch evaluation (branch :151-199).
 
     python main.py <the flags call_variants.sh passes> --test_file X.hdf --modelload CKPT \
         --save_vcf_records --save_vcf_records_file OUT/model_test.vcf --sample_vcf OUT/candidates.vcf
@@ -7,8 +8,9 @@
 Reads the candidate HDF5 (schema of tools/convert_bam_single_reads.py), scores every site with the
 MI355X-native DAN forward and writes ``OUT/epoch1_model_test.vcf`` exactly where and how the reference does
 (dl4vc/utils.py:146-178).  ``--gpus N`` starts one process per GPU over contiguous site shards and
-concatenates the part files on the host; there is no collective on this path.  Training flags are parsed
-(the pipeline script passes them) and ignored; ``--train_file`` is rejected: training is out of scope.
+concatenates the part files on the host; there is no collective on this path.  With ``--train_file`` the flags of
+train_variant_caller.sh:101-151 drive ``dl4vc_amd/trainer.py`` (one process per GPU, one RCCL all-reduce of the flat
+gradient buffer per step); training options outside the published script's path are refused, never ignored.
 """
 from __future__ import annotations
 
@@ -38,11 +40,133 @@ def child_devices(n: int):
     return have[:n]
 
 
+def train_main(args, argv) -> int:
+    """main.py:60-80,114-117,151-199: train for --epochs, evaluate on --test_file after every epoch, save checkpoints."""
+    import numpy as np
+    assert args.train_file[-3:] == "hdf", "Train dataset must be in HDF format"                   # main.py:66
+    assert args.test_file[-3:] == "hdf", "Test dataset must be in HDF format"
+    refused = [("--augment-single-reads", args.augment_single_reads), ("--augment-reference", args.augment_reference),
+               ("--reads-dynamic-downsample-rate", args.reads_dynamic_downsample_rate > 0), ("--rm_var_reads_rate", args.rm_var_reads_rate > 0),
+               ("--rm_non_var_reads_rate", args.rm_non_var_reads_rate > 0),
+               ("--training_use_directional_augmentation", args.training_use_directional_augmentation),
+               ("--train-trust-region-table", bool(args.train_trust_region_table)), ("--gatk-table", bool(getattr(args, "gatk_table", "")))]
+    bad = [n for n, on in refused if on]
+    if bad:
+        raise SystemExit("training option(s) %s are not supported (off in train_variant_caller.sh:101-151): refusing rather than "
+                         "silently training something else" % ", ".join(bad))
+    if args.precision != "fp32":
+        raise SystemExit("training runs in fp32 only")
+    from dl4vc_amd.config import DanConfig
+    from dl4vc_amd.train import DanTrainer, TrainHyper
+    from dl4vc_amd.trainer import train_epoch, evaluate, save_checkpoint, checkpoint_state
+    from dl4vc_amd.train_data import EasyExampleSampler
+    from dl4vc_amd.hdf5io import CandidateFile
+    from dl4vc_amd.model import DanNet, load_checkpoint
+    from dl4vc_amd.vcf import start_scored_vcf, scored_vcf_path
+    from dl4vc_amd.inference import select_sites
+    from dl4vc_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # one process per GPU (the reference: one process, nn.DataParallel over args.gpus devices, main.py:117)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        devices = child_devices(args.gpus)
+        procs = []
+        for g in range(args.gpus):
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=devices[g], HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(g), WORLD_SIZE=str(args.gpus),
+                       LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.pop("CUDA_VISIBLE_DEVICES", None)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise SystemExit("training rank failed: %s" % rcs)
+        return 0
+    dist = all_reduce = gather = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("DL4VC_DIST_BACKEND", "nccl")        # (tests rehearse two ranks on one GPU over gloo)
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        all_reduce = dist.all_reduce
+
+        def gather(item):
+            out = [None] * world
+            dist.all_gather_object(out, item)
+            return out
+
+    cfg = DanConfig.from_args(args)
+    hyper = TrainHyper.from_args(args)
+    print("Train on %d rank(s); lr %s, batch %d, dropout %s" % (world, hyper.lr, args.batch_size, hyper.dropout))
+    per_rank = -(-args.batch_size // world)
+    trainer = DanTrainer(cfg, hyper, max_batch=per_rank, device_id=0)
+    if args.modelload:
+        print("Loading model checkpoint from {}".format(args.modelload))
+        trainer.load_state_dict(load_checkpoint(args.modelload))
+    else:
+        trainer.load_state_dict(synth.torch_default_init(cfg, seed=args.seed, dropout_keys=hyper.dropout > 0))
+    best_loss = None
+    with CandidateFile(args.train_file) as train_src, CandidateFile(args.test_file) as test_src:
+        holdout = None
+        if args.train_holdout_chromosomes:
+            holdout = np.zeros(len(train_src), bool)
+            holdout[select_sites(args.train_file, args.train_holdout_chromosomes)] = True
+        # every rank draws the same epoch order (same seed) and takes its DataParallel-style share of every batch
+        sampler = EasyExampleSampler(len(train_src), close_keep=min(1.0, args.close_examples_sample_rate), holdout=holdout,
+                                     rng=np.random.RandomState(args.seed))
+        test_idx = select_sites(args.test_file, args.test_holdout_chromosomes) if args.test_holdout_chromosomes else None
+        for epoch in range(1, args.epochs + 1):
+            s = time.time()
+            print("Train Epoch: %d lr: [%s] on %d GPUs!" % (epoch, trainer.hyper.lr, world))
+            train_epoch(trainer, train_src, sampler, hyper, args.batch_size, epoch, reads_seed=args.reads_seed,
+                        max_batches=args.max_train_batches, keep_candidate_af=args.aux_keep_candidate_af, rank=rank, world=world,
+                        all_reduce=all_reduce, gather=gather, log_interval=args.log_interval,
+                        log=lambda m: print(m, end="\r"))
+            print("\n\tTime elapsed for training {:.4f}\n".format(time.time() - s), flush=True)
+            s_eval = time.time()
+            trainer.set_lr(trainer.hyper.lr * args.lr_decay)                                      # main.py:166
+            if epoch <= args.epochs_skip_eval:
+                print("Skipping eval for epoch %d" % epoch)
+                continue
+            if rank == 0:
+                net = DanNet(cfg, device_id=0, max_batch=args.test_batch_size).load_state_dict(trainer.state_dict())
+                out = None
+                if args.save_vcf_records:
+                    assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"
+                    if args.sample_vcf:
+                        out_path = start_scored_vcf(args.sample_vcf, args.save_vcf_records_file, epoch)
+                    else:
+                        out_path = scored_vcf_path(args.save_vcf_records_file, epoch)
+                        open(out_path, "w").close()
+                    out = open(out_path, "a")
+                curloss = evaluate(net, test_src, hyper, args.test_batch_size, write=out.write if out else None,
+                                   reads_seed=args.reads_seed, max_batches=args.max_test_batches, indices=test_idx)
+                if out:
+                    out.close()
+                net.close()
+                print("\nTest set: Average loss: {:.6f}\n".format(curloss))
+                is_best = best_loss is None or curloss < best_loss
+                best_loss = curloss if best_loss is None else min(curloss, best_loss)
+                save_checkpoint(checkpoint_state(trainer, epoch, best_loss), is_best, args.modelsave)   # main.py:194-199
+            print("\tTime elapsed for inference/testing {:.4f}".format(time.time() - s_eval))
+            print("\tTime elapsed overall {:.4f}\n".format(time.time() - s), flush=True)
+            if dist is not None:
+                dist.barrier()
+    trainer.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None) -> int:
     args = create_arg_parser().parse_args(argv)
     print(args)
     if args.train_file:
-        raise SystemExit("training (--train_file) is outside this implementation's scope (inference hot path only)")
+        return train_main(args, list(argv if argv is not None else sys.argv[1:]))
     assert args.test_file[-3:] == "hdf", "Test dataset must be in HDF format"                     # main.py:84
     print("\n\nRunning in inference only mode...\n\n")
     assert args.modelload is not None, "--modelload argument is required when running in inference only mode"   # main.py:215

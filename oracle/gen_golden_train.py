@@ -275,9 +275,43 @@ def run_case(name: str, spec: OracleSpec, n_sites: int, n_steps: int, seed: int,
     return worst
 
 
+def gen_sampler_fixture(d):
+    """The reference's AdjustableDataSampler (dataset.py:683-749) over hand-made tables, numpy's global generator seeded."""
+    import types
+    cases = []
+    rng = np.random.default_rng(5)
+    n = 40
+    scenarios = [
+        ("fresh", np.zeros(n, bool), np.zeros(n, bool), np.zeros(n, bool), False, True, 0.15, 11),
+        ("some_close", rng.random(n) < 0.5, np.zeros(n, bool), np.zeros(n, bool), False, True, 0.15, 12),
+        ("close_black_holdout", rng.random(n) < 0.4, rng.random(n) < 0.1, rng.random(n) < 0.2, False, True, 0.5, 13),
+        ("reverse_holdout_ordered", np.zeros(n, bool), rng.random(n) < 0.1, rng.random(n) < 0.3, True, False, 0.15, 14),
+        ("reverse_holdout_shuffled", np.zeros(n, bool), np.zeros(n, bool), rng.random(n) < 0.3, True, True, 0.15, 15),
+    ]
+    for name, close, black, hold, reverse, shuffle, keep, seed in scenarios:
+        FakeDataset = type("FakeDataset", (), {"__len__": lambda self: n})
+        ds = FakeDataset()
+        ds.close_examples, ds.blacklist, ds.chromosome_holdout = close.copy(), black.copy(), hold.copy()
+        args = types.SimpleNamespace(close_examples_sample_rate=keep)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sm = d.AdjustableDataSampler(ds, args=args, reverse_holdout=reverse, shuffle=shuffle)
+            np.random.seed(seed)
+            first = [int(i) for i in iter(sm)]
+            second = [int(i) for i in iter(sm)]            # a second epoch continues the same generator
+        cases.append({"name": name, "n": n, "close": close.tolist(), "blacklist": black.tolist(), "holdout": hold.tolist(),
+                      "reverse_holdout": reverse, "shuffle": shuffle, "close_keep": keep, "seed": seed,
+                      "epoch1": first, "epoch2": second, "len": len(sm)})
+    with open(os.path.join(GOLD, "train_sampler.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote train_sampler.json (%d scenarios)" % len(cases))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     mods = import_reference()
+    gen_sampler_fixture(mods[1])
+    if sys.argv[1:] == ["sampler"]:
+        return
     small = OracleSpec(reads=8, length=201, layers=7, c_init=16, c_final=16, bottleneck=4, fc_sizes=(6, 8))
     run_case("train_small", small, n_sites=6, n_steps=2, seed=300, mods=mods)
     tiny = dict(reads=4, length=201, c_init=8, c_final=8, bottleneck=2, fc_sizes=(4, 4))

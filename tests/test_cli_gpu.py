@@ -100,3 +100,53 @@ def test_bench_two_rank_launch_path():
     assert "cpu_baseline" not in rec
     ranks = [l for l in r.stderr.splitlines() if l.startswith("[bench rank")]
     assert len(ranks) == 2 and any("rank 0/2" in l for l in ranks) and any("rank 1/2" in l for l in ranks)
+
+
+TRAIN_FLAGS = ["--lr", "0.0002", "--grad-clip", "1.0", "--epochs", "1", "--log-interval", "1", "--label-smoothing", "0.001",
+               "--batch-size", "8", "--test-batch-size", "6", "--trust-snp-only", "--non-snp-train-weight", "2.0", "--fp-train-weight", "0.2",
+               "--auxillary-loss-weight", "1.0", "--auxillary-loss-bases-weight", "0.01", "--auxillary-loss-allele-weight", "0.001",
+               "--aux-keep-candidate-af", "--close_match_window", "2.0", "--focal_loss_alpha", "1.", "--focal_loss_gamma", "0.2",
+               "--close_examples_sample_rate", "0.15", "--model-ave-pool-layers", "2", "--model-init-conv-channels", "128",
+               "--model-final-conv-channels", "128", "--model-bottleneck-size", "32"]
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_main_py_training(tmp_path, gpus):
+    """main.py --train_file (main.py:151-199): one epoch of two batches, evaluation, checkpoint; the checkpoint then scores the
+    same sites identically through the inference-only mode.  gpus = 2: two ranks share device 0 and average their gradients
+    over gloo (RCCL refuses two ranks on one device) -- the data-parallel path of BASELINE config 4."""
+    import torch
+    from oracle.gen_golden_train import make_records
+    recs = make_records(16, 100, 900)
+    for name in ("train.hdf", "test.hdf"):
+        hdf5io.write_candidates(str(tmp_path / name), recs)
+    sample = str(tmp_path / "candidates.vcf")
+    open(sample, "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n")
+    env = dict(os.environ)
+    if gpus == 2:
+        env.update(DL4VC_FORCE_DEVICE0="1", DL4VC_DIST_BACKEND="gloo")
+    ck = str(tmp_path / "model.pth.tar")
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--train_file", str(tmp_path / "train.hdf"), "--test_file", str(tmp_path / "test.hdf"),
+           "--modelsave", ck, "--sample_vcf", sample, "--save_vcf_records", "--save_vcf_records_file", str(tmp_path / "model_test.vcf"),
+           "--gpus", str(gpus)] + MODEL_FLAGS + TRAIN_FLAGS
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Loss:" in r.stdout and "Test set: Average loss:" in r.stdout
+    # utils.py:180-186: os.path.splitext("model.pth.tar") = ("model.pth", ".tar")  ->  <base>_epoch<N><ext>, <base>_best<ext>
+    state = torch.load(str(tmp_path / "model.pth_epoch1.tar"), map_location="cpu", weights_only=False)
+    assert os.path.isfile(str(tmp_path / "model.pth_best.tar"))
+    assert state["epoch"] == 1 and np.isfinite(state["best_loss"]) and state["optimizer"]["step"] == 2
+    sdk = state["state_dict"]
+    assert all(k.startswith("module.") for k in sdk) and "module.conv2hidden.1.weight" in sdk and "module.bn1D_layers.3.running_var" in sdk
+    assert all(torch.isfinite(v).all() for v in sdk.values())
+    scored = open(str(tmp_path / "epoch1_model_test.vcf")).read().splitlines()
+    assert len([l for l in scored if not l.startswith("#")]) == 16
+    # the saved checkpoint in inference-only mode reproduces the epoch's evaluation scores
+    out2 = tmp_path / "again"
+    out2.mkdir()
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--test_file", str(tmp_path / "test.hdf"), "--modelload", str(tmp_path / "model.pth_best.tar"),
+           "--sample_vcf", sample, "--save_vcf_records", "--save_vcf_records_file", str(out2 / "model_test.vcf"), "--compute-empty-rows"] + MODEL_FLAGS
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    again = open(str(out2 / "epoch1_model_test.vcf")).read().splitlines()
+    assert again == scored
