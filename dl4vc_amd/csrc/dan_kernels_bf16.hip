@@ -275,11 +275,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         // whole read (and pool image) in flight at once, then convert + store (see the fp32 kernel's prologue)
         const int n4 = L * (CPAD / 4);
         constexpr int NPF = (G::MPOS_ * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;
-        v4f vy[NPF];
+        v4f vy[NPF], vp[NPF];                                    // the read AND its site's pool image in flight together
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * SEG_THREADS;
             vy[k] = (i < n4) ? src[i] : splat4(0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            vp[k] = (pl && i < n4) ? pl[i] : splat4(0.f);
         }
         // while the read is in flight: zero the rows it does not cover (halo rows and rows >= L, both planes) and stage
         // the constants
@@ -291,17 +296,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
             *(v4f*)(xs + pl_i * G::PLANE + row * S16 + c8 * 8) = splat4(0.f);
         }
         stage_constants();
-        if (pl) {
-#pragma unroll
-            for (int k = 0; k < NPF; ++k) {
-                const int i = tid + k * SEG_THREADS;
-                if (i < n4) vy[k] += pl[i];
-            }
-        }
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * SEG_THREADS;
-            if (i < n4) store_cell<SPLIT, G::PLANE>(xs + (HALO + (i >> 5)) * S16 + (i & 31) * 4, vy[k]);
+            if (i < n4) store_cell<SPLIT, G::PLANE>(xs + (HALO + (i >> 5)) * S16 + (i & 31) * 4, vy[k] + vp[k]);
         }
     }
     __syncthreads();

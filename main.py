@@ -230,10 +230,13 @@ def main(argv=None) -> int:
         target = part_path(out_final, shard_i)
     else:
         target = out_final + ".records"
+    t_loop = time.time()
     n = run_shard(net, args.test_file, target, shard_i, shard_n, sites_per_launch=args.sites_per_launch,
                   reads_seed=args.reads_seed, use_var_type_threshold=args.use_var_type_threshold,
                   holdout_chromosomes=holdout, site_limit=site_limit, log=lambda m: print(m, end="\r"))
+    t_loop = time.time() - t_loop
     net.close()
+    print("\nscoring loop (HDF5 read + assembly + forward + VCF text): %d sites in %.2f s = %.0f sites/s" % (n, t_loop, n / max(t_loop, 1e-9)))
     if shard_n == 1:
         if args.sample_vcf:
             start_scored_vcf(args.sample_vcf, out_base)

@@ -14,7 +14,8 @@ int main(int argc, char** argv) {
     const int l_begin = argc > 2 ? atoi(argv[1]) : 2, l_end = argc > 2 ? atoi(argv[2]) : 7;
     const int precision = argc > 3 ? atoi(argv[3]) : 0;
     const int wino = argc > 4 ? atoi(argv[4]) : 0;
-    const int R = 64, L = 201, sites = 64, layers = 7, nwg = sites * R;
+    const int L = argc > 5 ? atoi(argv[5]) : 201;
+    const int R = 64, sites = 64, layers = 7, nwg = sites * R;
     std::vector<float> wl((size_t)layers * LAYER_STRIDE);
     srand(1);
     for (auto& v : wl) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
