@@ -379,7 +379,9 @@ def main():
         # HBM traffic of the dominant kernel: measured by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
         # of this same command and committed under profiles/ (PMC collection cannot run inside the timed process)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))      # the newest round's PMC passes
+        tpath = tfiles[-1] if tfiles else ""
         if os.path.isfile(tpath) and cfg.reads == 64 and not args.chunk_sites and cfg.precision == 0 and cfg.length == 201:
             with open(tpath) as f:
                 traffic = int(json.load(f)["segment_kernel_bytes_per_launch"]["total"])

@@ -94,11 +94,25 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
         const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * a.s1_stride);
         const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)row * L * a.s1_stride) : nullptr;
         const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
-        for (int i = tid; i < n4; i += SEG_THREADS) {
-            const int p = i / vpr, c4 = i - p * vpr;
-            v4f v = load_transform(s1[i], s2 ? s2[i] : splat(0.f), a.coef, c4 * 4, a.mask_src2);
-            if (pl) v += pl[i];
-            *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = v;
+        // the whole read (and its second tensor / pool image) in flight at once, then transform + store: a loop of dependent
+        // load -> LDS store round trips leaves one CU streaming at a few loads per latency
+        constexpr int NP = (MPOS * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;     // 13
+        v4f r1[NP], r2[NP], r3[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            const bool ok = i < n4;
+            r1[k] = ok ? s1[i] : splat(0.f);
+            r2[k] = (ok && s2) ? s2[i] : splat(0.f);
+            r3[k] = (ok && pl) ? pl[i] : splat(0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            if (i < n4) {
+                const int p = i / vpr, c4 = i - p * vpr;
+                *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = load_transform(r1[k], r2[k], a.coef, c4 * 4, a.mask_src2) + r3[k];
+            }
         }
     }
     __syncthreads();
@@ -229,19 +243,31 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
         const int site = row / a.R;
         for (int p0 = 0; p0 < L; p0 += WG_CH) {
             __syncthreads();                                     // the previous chunk's MFMAs are done with the images
-            // ---- A rows [p0, p0 + WG_CH)
+            // ---- A rows [p0, p0 + WG_CH): every load of the chunk in flight before the first is consumed (a staging loop of
+            // dependent load -> transform -> LDS store round trips was half of this kernel's time)
             {
                 const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * a.a_stride);
                 const v4f* s2 = a.a2 ? (const v4f*)(a.a2 + (size_t)row * L * a.a_stride) : nullptr;
-                for (int i = tid; i < WG_CH * vpa; i += SEG_THREADS) {
+                constexpr int NIT = (WG_CH * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;       // 7 at 128 channels
+                v4f r1[NIT], r2[NIT];
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
                     const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
-                    v4f v = splat(0.f);
-                    if (p < L) {
-                        const size_t g = (size_t)p * vpa + c4;
-                        v = load_transform(s1[g], s2 ? s2[g] : splat(0.f), a.a_coef, c4 * 4, a.a_mask);
+                    const bool ok = i < WG_CH * vpa && p < L;
+                    const size_t g = (size_t)p * vpa + c4;
+                    r1[k] = ok ? s1[g] : splat(0.f);
+                    r2[k] = (ok && s2) ? s2[g] : splat(0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
+                    if (i < WG_CH * vpa) {
+                        const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                        const v4f v = (p < L) ? load_transform(r1[k], r2[k], a.a_coef, c4 * 4, a.a_mask) : splat(0.f);
+                        *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
+                        bsum += v;
                     }
-                    *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
-                    bsum += v;
                 }
             }
             // ---- B rows [p0 - HALO, p0 + WG_CH + HALO)
@@ -253,16 +279,25 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
             } else {
                 const v4f* b1 = (const v4f*)(a.b1 + (size_t)row * L * CPAD);
                 const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
-                for (int i = tid; i < BROWS * (CPAD / 4); i += SEG_THREADS) {
+                constexpr int NIT = BROWS * (CPAD / 4) / SEG_THREADS;                            // 7
+                static_assert(NIT * SEG_THREADS == BROWS * (CPAD / 4), "B staging covers the image exactly");
+                v4f r1[NIT], r2[NIT];
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
                     const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
-                    v4f v = splat(0.f);
-                    if (p >= 0 && p < L) {
-                        const size_t g = (size_t)p * (CPAD / 4) + c4;
-                        v = b1[g];
-                        if (a.b_coef) v = *(const v4f*)(a.b_coef + c4 * 4) * v + *(const v4f*)(a.b_coef + 2 * CPAD + c4 * 4);
-                        if (pl4) v += pl4[g];
-                    }
-                    *(v4f*)(sb + pl * WG_S + c4 * 4) = v;
+                    const bool ok = p >= 0 && p < L;
+                    const size_t g = (size_t)p * (CPAD / 4) + c4;
+                    r1[k] = ok ? b1[g] : splat(0.f);
+                    r2[k] = (ok && pl4) ? pl4[g] : splat(0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
+                    const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
+                    v4f v = r1[k];
+                    if (a.b_coef && p >= 0 && p < L) v = *(const v4f*)(a.b_coef + c4 * 4) * v + *(const v4f*)(a.b_coef + 2 * CPAD + c4 * 4);
+                    *(v4f*)(sb + pl * WG_S + c4 * 4) = v + r2[k];
                 }
             }
             __syncthreads();

@@ -150,3 +150,24 @@ def test_main_py_training(tmp_path, gpus):
     assert r.returncode == 0, r.stderr[-2000:]
     again = open(str(out2 / "epoch1_model_test.vcf")).read().splitlines()
     assert again == scored
+
+
+def test_bench_train_two_rank_launch_path():
+    """bench.py --mode train under torch.distributed.run with two ranks (both on device 0, gloo): the data-parallel branch --
+    one all-reduce of the flat gradient buffer per step -- runs before the driver's multi-GPU bench meets it."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_FORCE_DEVICE0="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--train-batch", "4", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["unit"] == "sites/s" and rec["config"]["sites_per_gpu_per_step"] == 4
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 8) < 0.01 and np.isfinite(rec["last_step"]["loss"])
