@@ -98,6 +98,15 @@ void launch_final_pool_bwd(const float* y, const float* dfeat, long long fs, flo
 // dh[layer][row][p][c] = sum_o dhw[row][layer][o] * Wc[layer][o][c][p], dhw = dfeat_hw * (feat_hw > 0)
 void launch_highway_bwd(const float* dfeat, const float* feat, long long fs, int feat_off, const float* wc, long long wc_layer,
                         float* dh, long long dh_layer, int n_sites, int R, int L, int H, int layers, hipStream_t s);
+// dhw[layer][row][HPAD] = dfeat_hw * (feat_hw > 0): with it both highway products are plain GEMMs (launch_gemm):
+//   dh[layer][row][e] = dhw[row][:] . WcT[e][:]            (M = rows, N = L*HPAD, K = HPAD; both K-contiguous)
+//   gWcT[o][e]        = sum_rows dhw[row][o] h[row][e]      (M = HPAD, N = L*HPAD, K = rows; both K-slow, split-K)
+void launch_highway_dhw(const float* dfeat, const float* feat, long long fs, int feat_off, float* dhw, int n_sites, int R, int H,
+                        int layers, hipStream_t s);
+void launch_highway_wc_transpose(const float* t, float* g_wc, int L, int H, hipStream_t s);
+void launch_highway_bias_grad(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial /*[64][HPAD]*/,
+                              float* g_bc, int n_sites, int R, int H, hipStream_t s);
+// (VALU forms, kept as the reference implementation of the two products)
 // gWc[layer][o][c][p] = sum_rows dhw * h[layer][row][p][c];  gbc[layer][o] = sum_rows dhw   (split over row blocks -> partials)
 void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, int feat_off, const float* h, long long h_layer,
                           float* partial, float* g_wc, long long wc_layer, float* g_bc, int n_sites, int R, int L, int H, int layers,

@@ -599,6 +599,34 @@ __device__ __forceinline__ float dhw_of(const float* dfeat, const float* feat, l
     return feat[i] > 0.f ? dfeat[i] : 0.f;
 }
 
+// dhw[layer][row][o] (zero for o >= H): the operand of both highway GEMMs
+__global__ __launch_bounds__(256) void highway_dhw_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
+                                                          int feat_off, float* __restrict__ dhw, int n_rows, int R, int H) {
+    const int layer = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows * HPAD) return;
+    const int row = idx >> 5, o = idx & 31;
+    dhw[(size_t)layer * n_rows * HPAD + idx] = o < H ? dhw_of(dfeat, feat, fs, feat_off, layer, H, R, row, o) : 0.f;
+}
+
+void launch_highway_dhw(const float* dfeat, const float* feat, long long fs, int feat_off, float* dhw, int n_sites, int R, int H,
+                        int layers, hipStream_t s) {
+    const int n_rows = n_sites * R;
+    hipLaunchKernelGGL(highway_dhw_kernel, dim3((n_rows * HPAD + 255) / 256, layers), dim3(256), 0, s, dfeat, feat, fs, feat_off, dhw, n_rows, R, H);
+}
+
+// gWc[o][c][p] = t[o][p*HPAD + c]  (the wgrad GEMM's output is [o][e = (p, c)]: the torch layout wants (o, c, p))
+__global__ __launch_bounds__(256) void highway_wc_transpose_kernel(const float* __restrict__ t, float* __restrict__ g_wc, int L, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= H * H * L) return;
+    const int p = idx % L, c = (idx / L) % H, o = idx / (L * H);
+    g_wc[idx] = t[(size_t)o * L * HPAD + p * HPAD + c];
+}
+
+void launch_highway_wc_transpose(const float* t, float* g_wc, int L, int H, hipStream_t s) {
+    hipLaunchKernelGGL(highway_wc_transpose_kernel, dim3((H * H * L + 255) / 256), dim3(256), 0, s, t, g_wc, L, H);
+}
+
 constexpr int HB_ROWS = 8;
 __global__ __launch_bounds__(256) void highway_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, long long fs,
                                                           int feat_off, const float* __restrict__ wc, long long wc_layer,
@@ -705,6 +733,15 @@ __global__ __launch_bounds__(256) void highway_wgrad_reduce_kernel(const float* 
     float sum = 0.f;
     for (int sp = 0; sp < HW_SPLITS; ++sp) sum += partial[((size_t)sp * HPAD + o) * n_e + e];
     g_wc[idx] = sum;
+}
+
+// gbc[o] = sum over rows of dhw[row][o] for ONE layer (feat_off points at that layer's block of the feature row)
+void launch_highway_bias_grad(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial, float* g_bc,
+                              int n_sites, int R, int H, hipStream_t s) {
+    constexpr int BIAS_BLOCKS = 64;
+    const int n_rows = n_sites * R;
+    hipLaunchKernelGGL(highway_bias_partial_kernel, dim3(BIAS_BLOCKS), dim3(256), 0, s, dfeat, feat, fs, feat_off, partial, n_rows, R, H);
+    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3(1), dim3(64), 0, s, partial, BIAS_BLOCKS, g_bc, H);
 }
 
 void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, int feat_off, const float* h, long long h_layer,
@@ -1044,19 +1081,23 @@ __device__ float focal_site(const float* x, int n, int tgt, float wgt, const flo
 
 __device__ const float BASE_CW[VOCAB] = {0.001f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.001f, 0.001f, 1.f, 0.001f};      // trainer.py:312-313
 
+// head outputs (model.py:919-921,953-958): one workgroup per site, one wave-slice per head
+__global__ __launch_bounds__(64) void heads_logits_kernel(LossArgs a) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t >= NHEAD) return;
+    const float* x = a.hidden + (size_t)b * a.hid_stride;
+    const float* w = a.wh + (size_t)t * a.hid;
+    float acc = 0.f;
+    for (int k = 0; k < a.hid; ++k) acc = fmaf(x[k], w[k], acc);
+    a.logits[(size_t)b * NHEAD + t] = acc + a.bh[t];
+}
+
 __global__ __launch_bounds__(256) void heads_loss_kernel(LossArgs a, float* site_terms) {
     __shared__ float red[2][256];
     const int tid = threadIdx.x;
-    // ---- head outputs (model.py:919-921,953-958) and the cross-entropy normalisers sum_b w[y_b]
+    // ---- the cross-entropy normalisers sum_b w[y_b]
     float wsum_b = 0.f, wsum_r = 0.f;
     for (int b = tid; b < a.B; b += 256) {
-        const float* x = a.hidden + (size_t)b * a.hid_stride;
-        for (int t = 0; t < NHEAD; ++t) {
-            const float* w = a.wh + (size_t)t * a.hid;
-            float acc = 0.f;
-            for (int k = 0; k < a.hid; ++k) acc = fmaf(x[k], w[k], acc);
-            a.logits[(size_t)b * NHEAD + t] = acc + a.bh[t];
-        }
         wsum_b += BASE_CW[min((int)a.var_base[b], VOCAB - 1)];
         wsum_r += BASE_CW[min((int)a.var_ref[b], VOCAB - 1)];
     }
@@ -1129,6 +1170,7 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(LossArgs a, float* site
 }
 
 void launch_heads_loss(const LossArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(heads_logits_kernel, dim3(a.B), dim3(64), 0, s, a);
     hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(256), 0, s, a, a.site_terms);
 }
 
@@ -1190,10 +1232,18 @@ void launch_sumsq(const float* g, long long n, double* block_partials, int* n_bl
     hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, g, n, block_partials);
 }
 
-__global__ __launch_bounds__(64) void clip_coef_kernel(const double* __restrict__ bp, int nb, float clip, float* out) {
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ bp, int nb, float clip, float* out) {
+    __shared__ double red[256];
+    double part = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) part += bp[i];            // fixed assignment, fixed tree: deterministic
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
-    double sum = 0.0;
-    for (int i = 0; i < nb; ++i) sum += bp[i];
+    const double sum = red[0];
     const float norm = (float)sqrt(sum);
     float coef = 1.f;
     if (clip > 0.f) coef = fminf(1.f, clip / (norm + 1e-6f));
@@ -1202,7 +1252,7 @@ __global__ __launch_bounds__(64) void clip_coef_kernel(const double* __restrict_
 }
 
 void launch_clip_coef(const double* block_partials, int n_blocks, float clip, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, s, block_partials, n_blocks, clip, out);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, block_partials, n_blocks, clip, out);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,

@@ -90,6 +90,9 @@ struct dan_trainer {
     float *d_du = nullptr, *d_g[2] = {nullptr, nullptr}, *d_dn = nullptr, *d_dpool = nullptr, *d_dh = nullptr;
     float *d_partial = nullptr, *d_bias_partial = nullptr, *d_hw_partial = nullptr, *d_emb_partial = nullptr;
     float* d_clip = nullptr;
+    float* d_dhw = nullptr;                                    // [layers][rows][HPAD]
+    float* d_split_hw = nullptr;                               // split-K partials of the highway weight-gradient GEMM
+    long long split_hw_floats = 0;
     float* d_split_ws = nullptr;                               // split-K partials of the forward FC GEMMs
     long long split_ws_floats = 0;
     double* d_emb_bp = nullptr;
@@ -359,6 +362,10 @@ int dan_train_finalize(dan_trainer_t* t) {
         (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD + 64 * HPAD, false)) ||
         (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
         (rc = talloc(t, &t->d_clip, 4))) return rc;
+    if (H > 0) {
+        t->split_hw_floats = (long long)8 * HPAD * L * HPAD;
+        if ((rc = talloc(t, &t->d_dhw, (size_t)NL * rows * HPAD, false)) || (rc = talloc(t, &t->d_split_hw, (size_t)t->split_hw_floats, false))) return rc;
+    }
     t->split_ws_floats = (long long)32 * B * std::max(t->n0, t->n1);
     if ((rc = talloc(t, &t->d_split_ws, (size_t)t->split_ws_floats, false))) return rc;
     HIPT(t, hipDeviceSynchronize());
@@ -541,12 +548,20 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
     // highway compression
     const int hw_off = 2 * c.c_final * L;
     if (H > 0) {
-        launch_highway_bwd(t->d_dfeat, t->d_feat, t->F_stride, hw_off, t->d_wct, (long long)L * HPAD * HPAD, t->d_dh, h_layer, B, R, L, H, NL, s);
-        // gradient tensors of the compression layers are NOT contiguous across layers in the flat buffer: one launch per layer
+        // dhw = dfeat_hw * (feat_hw > 0) as [layer][row][HPAD]; then per layer two tiled MFMA GEMMs (launch_gemm) and a column sum
+        const int NE = L * HPAD;
+        launch_highway_dhw(t->d_dfeat, t->d_feat, t->F_stride, hw_off, t->d_dhw, B, R, H, NL, s);
         for (int l = 0; l < NL; ++l) {
             const LayerP& lp = t->layers[l];
-            launch_highway_wgrad(t->d_dfeat + (size_t)0, t->d_feat, t->F_stride, hw_off + l * H * R, t->d_h + (size_t)l * h_layer, 0, t->d_hw_partial,
-                                 gp(t, lp.cmp_w), 0, gp(t, lp.cmp_b), B, R, L, H, 1, 0, s);
+            const float* dhw = t->d_dhw + (size_t)l * n_rows * HPAD;
+            // dh[row][e] = sum_o dhw[row][o] WcT[e][o]
+            launch_gemm(dhw, HPAD, 0, t->d_wct + (size_t)l * L * HPAD * HPAD, HPAD, 0, nullptr, t->d_dh + (size_t)l * h_layer, NE, n_rows, NE, HPAD, 0,
+                        nullptr, 0, s);
+            // gWcT[o][e] = sum_rows dhw[row][o] h[row][e]   (K = rows: split-K), then to the torch layout (o, c, p)
+            launch_gemm(dhw, HPAD, 1, t->d_h + (size_t)l * h_layer, NE, 1, nullptr, t->d_hw_partial, NE, HPAD, NE, n_rows, 0, t->d_split_hw,
+                        t->split_hw_floats, s);
+            launch_highway_wc_transpose(t->d_hw_partial, gp(t, lp.cmp_w), L, H, s);
+            launch_highway_bias_grad(t->d_dfeat, t->d_feat, t->F_stride, hw_off + l * H * R, t->d_bias_partial, gp(t, lp.cmp_b), B, R, H, s);
         }
     }
     // final max + mean pool (model.py:824-839)

@@ -158,3 +158,26 @@ def test_device_dropout_masks_and_errors():
         DanTrainer(cfg, TrainHyper(), max_batch=2).load_state_dict(bad)
     with pytest.raises(RuntimeError, match="fp32"):
         DanTrainer(DanConfig(reads=6, precision=2), TrainHyper(), max_batch=2)
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """Forty steps on one fixed batch (device-drawn dropout masks, torch-default-style initial weights): the loss the kernels
+    minimise must fall -- an integration check that forward, backward, clipping and Adam pull in the same direction."""
+    cfg = DanConfig(reads=16, c_init=32, c_final=32, bottleneck=8, fc_sizes=(32, 16))
+    sd = synth.torch_default_init(cfg, seed=2)
+    B = 8
+    batch = synth.make_sites(B, reads=cfg.reads, seed=5)
+    rng = np.random.default_rng(6)
+    hp = TrainHyper(lr=2e-3)
+    tg = {"label": rng.integers(0, 3, B), "var_type": rng.integers(0, 3, B), "allele_freq": rng.random(B).astype(np.float32),
+          "coverage": rng.integers(5, 16, B).astype(np.float32), "var_base_enum": rng.integers(1, 6, B),
+          "var_ref_enum": rng.integers(1, 5, B), "is_snp": rng.integers(0, 2, B)}
+    tg["weight"] = example_weights(tg["is_snp"], hp)
+    tr = DanTrainer(cfg, hp, max_batch=B).load_state_dict(sd)
+    losses = [tr.train_step(batch.arrays(), tg, seed=11)["loss"] for _ in range(40)]
+    assert np.isfinite(losses).all()
+    first, last = np.mean(losses[:4]), np.mean(losses[-4:])
+    print("loss %.4f -> %.4f over 40 steps" % (first, last))
+    assert last < 0.6 * first, (first, last)
+    assert tr.query("step") == 40
+    tr.close()
