@@ -218,10 +218,13 @@ void launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
 // Wave w owns output tile w of A (OWN_O) and every input tile of B and tap, or input tile w of B and both output tiles of
 // A (bottleneck: A is 32 wide).  MFMA k index = position: lane group kk supplies position 4 k4 + kk, so the two k-groups
 // of a 32-lane half read rows one apart: with the 144-float row stride those are 16 banks apart -- conflict-free ds_read_b32.
-template <int TAPS, bool OWN_O>
+// CT: input tiles of B an OWN_O wave walks (8, or 3 for the 48-channel encoded input) -- a compile-time count, so that the
+// k-step body is straight-line code: all of a step's LDS reads issued, then its MFMAs (with the count at run time every tile
+// was a branch and every MFMA waited for its own read)
+template <int TAPS, bool OWN_O, int CT>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(WgradArgs a) {
     constexpr int BROWS = WG_CH + 2 * HALO;
-    constexpr int NB = OWN_O ? KGC : 1, NA = OWN_O ? 1 : 2;
+    constexpr int NB = OWN_O ? CT : 1, NA = OWN_O ? 1 : 2;
     __shared__ __attribute__((aligned(16))) float sa[WG_CH * WG_S];
     __shared__ __attribute__((aligned(16))) float sb[BROWS * WG_S];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -302,25 +305,24 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
             }
             __syncthreads();
             if (active) {
+                const float* pa = sa + kk * WG_S + i16;
+                const float* pb = sb + (HALO + kk) * WG_S + i16;
+                const int dstep = a.dil * WG_S;
+#pragma unroll 2
                 for (int k4 = 0; k4 < WG_CH / 4; ++k4) {
-                    const int r = 4 * k4 + kk;
-                    float av[NA];
+                    float av[NA], bv[TAPS][NB];
 #pragma unroll
-                    for (int x = 0; x < NA; ++x) av[x] = sa[r * WG_S + 16 * (OWN_O ? wave : x) + i16];
+                    for (int x = 0; x < NA; ++x) av[x] = pa[4 * k4 * WG_S + 16 * (OWN_O ? wave : x)];
 #pragma unroll
-                    for (int t = 0; t < TAPS; ++t) {
-                        const float* brow = sb + (HALO + r + (t - TAPS / 2) * a.dil) * WG_S + i16;
+                    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                        for (int y = 0; y < NB; ++y) {
-                            if (OWN_O && y >= a.c_tiles) continue;
-                            const float bv = brow[16 * (OWN_O ? y : wave)];
+                        for (int y = 0; y < NB; ++y) bv[t][y] = pb[4 * k4 * WG_S + (t - TAPS / 2) * dstep + 16 * (OWN_O ? y : wave)];
 #pragma unroll
-                            for (int x = 0; x < NA; ++x) {
-                                if (!OWN_O && x >= a.o_tiles) continue;
-                                acc[t][x][y] = mfma16(av[x], bv, acc[t][x][y]);
-                            }
-                        }
-                    }
+                    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                        for (int y = 0; y < NB; ++y)
+#pragma unroll
+                            for (int x = 0; x < NA; ++x) acc[t][x][y] = mfma16(av[x], bv[t][y], acc[t][x][y]);
                 }
             }
         }
@@ -359,9 +361,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
 int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
     const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
     const dim3 grid((unsigned)wgs), blk(SEG_THREADS);
-    if (a.o_tiles <= 2 && a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, false>), grid, blk, 0, s, a);
-    else if (a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, true>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((train_wgrad_kernel<3, true>), grid, blk, 0, s, a);
+    if (a.o_tiles <= 2 && a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, false, 1>), grid, blk, 0, s, a);   // A 32 wide: both its tiles per wave
+    else if (a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, true, KGC>), grid, blk, 0, s, a);
+    else if (a.c_tiles <= KG0) hipLaunchKernelGGL((train_wgrad_kernel<3, true, KG0>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((train_wgrad_kernel<3, true, KGC>), grid, blk, 0, s, a);
     return wgs;
 }
 
