@@ -413,6 +413,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
+                         "frac_definition": "algorithmic direct-convolution FLOPs / kernel time / peak (the contract's definition; an "
+                                            "EFFECTIVE rate when the Winograd form runs); matrix-pipe utilisation = executed_frac",
                          "conv_algo": "winograd_f23" if cfg.winograd_applies() else "direct",
                          "executed": round(executed, 3) if executed else None,
                          "executed_frac": round(executed / peak, 4) if executed else None,
