@@ -142,4 +142,72 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2,3) core over the dilated positions (see the comment block above its use in dan_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+constexpr int MW = 7;                   // Winograd tiles per lane
+constexpr int WHB = 102;                // first position of the upper half's tiling
+__device__ __forceinline__ int wino_base(int lane) {
+    const int n = lane & 15;
+    const int c = n & 1, hf = (n >> 2) & 1, q = ((n >> 1) & 1) + 2 * (((n >> 3) ^ (n >> 2)) & 1);
+    return hf * WHB + 4 * q * MW + c;
+}
+
+// acc[m][k] += U_k[own 16 channels][all 128 in-channels] * V_k[tile m]
+typedef float v2f __attribute__((ext_vector_type(2)));
+// a - b as two v_pk_fma_f32 (b * m1 + a with m1 = -1.0 in a register the compiler cannot see through: hipcc turns a
+// v2f32 fsub, or an fma by a literal -1, into two scalar v_sub_f32; every VALU instruction costs the SIMD 3-5 cycles of
+// MFMA issue -- tools/ubench/mfma_valu.hip -- so the packed form halves the price of the input transform)
+__device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
+    const v2f lo = __builtin_elementwise_fma((v2f){b[0], b[1]}, m1, (v2f){a[0], a[1]});
+    const v2f hi = __builtin_elementwise_fma((v2f){b[2], b[3]}, m1, (v2f){a[2], a[3]});
+    return (v4f){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
+    v4f a_nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a_nxt[k] = a_first[k];
+    v4f xa = *(const v4f*)(xrow), xb = *(const v4f*)(xrow + 2 * LDS_S), xc = *(const v4f*)(xrow + 4 * LDS_S),
+        xd = *(const v4f*)(xrow + 6 * LDS_S);
+    float neg1 = -1.f;
+    asm volatile("" : "+v"(neg1));
+    const v2f m1 = {neg1, neg1};
+    for (int g = 0; g < KGC; ++g) {
+        v4f a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = a_nxt[k];
+        const int gn = (g + 1 < KGC) ? g + 1 : g;            // last step: harmless re-read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a_nxt[k] = wl[(size_t)(k * KGC + gn) * (KGC * 64)];
+        const float* xg = xrow + g * 16;
+        const float* xn = xrow + gn * 16;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            v4f v[4];
+            v[0] = pk_sub(xa, xc, m1); v[1] = xb + xc; v[2] = pk_sub(xc, xb, m1); v[3] = pk_sub(xb, xd, m1);
+            if (m + 1 < MW) {
+                xa = xc; xb = xd;
+                xc = *(const v4f*)(xg + (4 * m + 8) * LDS_S);
+                xd = *(const v4f*)(xg + (4 * m + 10) * LDS_S);
+            } else {
+                xa = *(const v4f*)(xn); xb = *(const v4f*)(xn + 2 * LDS_S);
+                xc = *(const v4f*)(xn + 4 * LDS_S); xd = *(const v4f*)(xn + 6 * LDS_S);
+            }
+            // MFMAs at s_setprio 3, the VALU/LDS stretch that forms the next V at 0: the arbiter then serves the other
+            // wave's MFMAs ahead of this wave's VALU stream (by default the OLDER wave's instructions of either kind come
+            // first, and its VALU batches stall the younger wave's MFMA issue).  tools/ubench/wino_loop.hip: 37.6 -> 36.4
+            // cycles per MFMA at the SIMD.
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[m][k] = mfma16(a[k][s], v[k][s], acc[m][k]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
+// LDS rows a Winograd GEMM may read: tiles past the window read beyond the activation rows (into whatever follows them)
+constexpr int WINO_ROWS_READ = HALO + WHB + 4 * (4 * MW - 1) + 1 + 4 + 1;
+
 }  // namespace dan

@@ -33,6 +33,8 @@ struct RowArgs {
     const float* pool_in;                   // [site][L][CPAD] added to every read of the site (model.py:742), or nullptr
     const float* w1;                        // packed A fragments [taps][kg][8][64][4], or nullptr
     int taps, kg, dil;
+    int wino;                               // 1: w1 holds the Winograd F(2,3) transform U [4][8][8][64][4] of a 3-tap, dilation-2,
+                                            //    128-channel kernel and the launch runs in that form (no second GEMM stage then)
     const float* bias1;                     // [CPAD] or nullptr
     int relu_out;
     const float *add1, *add2;               // row addends (CPAD stride) or nullptr
@@ -86,6 +88,8 @@ void launch_bn_backward_coef(const double* bp, int n_blocks, double n_pos, const
 //   W(o,c,t) = src[omap(o) * so + cmap(c) * sc + (flip ? taps-1-t : t) * st]  (0 outside n_out x n_in or where a map gives -1)
 void launch_pack_frag(float* dst, const float* src, int taps, int kg, int tiles, int n_out, int n_in, long long so, long long sc,
                       long long st, int flip, const int* omap, const int* cmap, hipStream_t s);
+// U[(o * n_in + c)][4] = Winograd F(2,3) transform of the 3-tap kernel at src[o*so + c*sc + t] (flip: taps reversed)
+void launch_wino_u(float* dst, const float* src, int n_out, int n_in, long long so, long long sc, int flip, hipStream_t s);
 // highway compression weights Wc[o][c][p] (torch (H,H,1,L)) -> the highway kernel's fragment order [2L][2][64][4]
 void launch_pack_wc(float* dst, const float* src, int H, int L, hipStream_t s);
 // WcT[p][c][o] = Wc[o][c][p] padded to HPAD x HPAD: the operand of launch_highway_bwd

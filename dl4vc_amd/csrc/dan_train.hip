@@ -75,15 +75,16 @@ __device__ __forceinline__ v4f load_transform(v4f s1, v4f s2, const float* coef,
 // ------------------------------------------------------------------------------------------------
 // T1: one layer-shaped step on the LDS-resident read
 // ------------------------------------------------------------------------------------------------
+constexpr int TR_LDS_ROWS = (WINO_ROWS_READ > LDS_ROWS ? WINO_ROWS_READ : LDS_ROWS);      // Winograd tiles past the window read a few rows on
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[LDS_ROWS * LDS_S];
+    __shared__ __attribute__((aligned(16))) float xs[TR_LDS_ROWS * LDS_S];
     __shared__ float sred[2][2][CPAD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.x;
     const int site = row / a.R;
     const int L = a.L;
-    for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+    for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
     __syncthreads();
     if (a.mode == 0) {
         EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
@@ -118,6 +119,62 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
     __syncthreads();
 
     const int pos = lane & 15, kk = lane >> 4;
+    const size_t rbase = (size_t)row * L * CPAD, sbase = (size_t)site * L * CPAD;
+    if (a.wino) {
+        // ---- 3 taps at dilation 2 in Winograd F(2,3) form (conv_gemm_wino of dan_device.h, the inference kernel's core: 4
+        // channel GEMMs per 2 outputs instead of 6).  Wave = one 16-channel output tile x all positions; MFMA column n of
+        // tile step m is the Winograd tile with base P = wino_base(lane) + 4 m, outputs y(P), y(P + 2).
+        const int wP0 = wino_base(lane);
+        const int wlim = ((lane >> 2) & 1) ? MPOS : WHB;            // positions this lane's tiling owns
+        const int chw = wave * 16 + kk * 4;
+        gv4f_ptr w_w = (gv4f_ptr)(a.w1) + wave * 64 + lane;
+        constexpr size_t KS = (size_t)KGC * (KGC * 64);
+        const v4f pre_w[4] = {w_w[0], w_w[KS], w_w[2 * KS], w_w[3 * KS]};
+        v4f acc4[MW][4];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc4[m][k] = splat(0.f);
+        conv_gemm_wino(acc4, xs + (HALO + wP0 - 2) * LDS_S + kk * 4, w_w, pre_w);
+        const v4f bias = a.bias1 ? *(const v4f*)(a.bias1 + chw) : splat(0.f);
+        v4f s0 = splat(0.f), s1 = splat(0.f);
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int p = wP0 + 4 * m + 2 * o;
+                if (p < wlim && p < L) {
+                    const size_t off = (size_t)p * CPAD + chw;
+                    v4f v = (o == 0 ? acc4[m][0] + acc4[m][1] + acc4[m][2] : acc4[m][1] - acc4[m][2] - acc4[m][3]) + bias;
+                    if (a.add1) v += *(const v4f*)(a.add1 + rbase + off);
+                    if (a.add2) v += *(const v4f*)(a.add2 + rbase + off);
+                    if (a.addb) v += *(const v4f*)(a.addb + sbase + off);
+                    if (a.relu_out) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    if (a.stats) {
+                        const v4f x = a.stat_aux ? *(const v4f*)(a.stat_aux + rbase + off) : v;
+                        s0 += v;
+                        s1 += v * x;
+                    }
+                    if (a.out1) *(v4f*)(a.out1 + rbase + off) = v;
+                }
+            }
+        if (a.stats) {                                           // every channel belongs to exactly one (wave, k-quarter, j)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s0[j], y = s1[j];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) { x += __shfl_xor(x, msk); y += __shfl_xor(y, msk); }
+                if (pos == 0) {
+                    a.stats[((size_t)row * 2 + 0) * CPAD + chw + j] = x;
+                    a.stats[((size_t)row * 2 + 1) * CPAD + chw + j] = y;
+                }
+            }
+        }
+        return;                                                  // (no bottleneck stage rides on the 3-tap launches)
+    }
     const int cq = wave & 3, ph = wave >> 2;
     const int m_base = ph * MTW, cnt = ph ? MT - MTW : MTW;
     int chb[NT];
@@ -140,7 +197,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
                 acc[m][n] = (m < cnt) ? *(const v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]) : splat(0.f);
     }
     // ---- epilogue
-    const size_t rbase = (size_t)row * L * CPAD, sbase = (size_t)site * L * CPAD;
     v4f s0[NT], s1v[NT], bias[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -505,6 +561,27 @@ void launch_pack_frag(float* dst, const float* src, int taps, int kg, int tiles,
     const long long total = (long long)taps * kg * tiles * 256;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dst, src, taps, kg, tiles, n_out, n_in,
                        so, sc, st, flip, omap, cmap);
+}
+
+// Winograd F(2,3) weight transform of a 3-tap kernel g = (g0, g1, g2):  U = [g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2],
+// formed in double.  dst[(o * n_in + c) * 4 + k];  g_t = src[o * so + c * sc + (flip ? 2 - t : t)]  (the data gradient uses the
+// flipped kernel with the roles of o and c exchanged through so / sc)
+__global__ __launch_bounds__(256) void wino_u_kernel(float* __restrict__ dst, const float* __restrict__ src, int n_out, int n_in,
+                                                     long long so, long long sc, int flip) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_out * n_in) return;
+    const int c = idx % n_in, o = idx / n_in;
+    const float* g = src + (long long)o * so + (long long)c * sc;
+    const double g0 = g[flip ? 2 : 0], g1 = g[1], g2 = g[flip ? 0 : 2];
+    float* u = dst + (size_t)idx * 4;
+    u[0] = (float)g0;
+    u[1] = (float)((g0 + g1 + g2) * 0.5);
+    u[2] = (float)((g0 - g1 + g2) * 0.5);
+    u[3] = (float)g2;
+}
+
+void launch_wino_u(float* dst, const float* src, int n_out, int n_in, long long so, long long sc, int flip, hipStream_t s) {
+    hipLaunchKernelGGL(wino_u_kernel, dim3((n_out * n_in + 255) / 256), dim3(256), 0, s, dst, src, n_out, n_in, so, sc, flip);
 }
 
 // highway kernel fragment order: dst[g = 2p + (c>>4)][n][lane][s] = Wc[o = 16n + (lane&15)][c = 16(g&1) + 4(lane>>4) + s][p]

@@ -69,6 +69,9 @@ struct dan_trainer {
     float* d_pe = nullptr;
     int *d_inv = nullptr, *d_canon = nullptr;                 // layer-1 channel maps: canonical -> reference (48), reference -> canonical
     std::vector<float*> pk_conv_f, pk_conv_d, pk_res_f, pk_res_d, pk_bot_f, pk_bot_d;
+    std::vector<float*> pk_wino_f, pk_wino_d;                 // Winograd F(2,3) forms of the conv / its data gradient (dilation-2 layers)
+    std::vector<int> wino_layer;
+    float* d_wino_u = nullptr;                                // [128][128][4] scratch of the weight transform
     float *d_wc_pk = nullptr, *d_wct = nullptr, *d_bc_pad = nullptr;
     float* d_bias = nullptr;                                  // [layers][3][CPAD]: conv bias, residual bias, bottleneck bias (padded)
     float *d_coef_f = nullptr, *d_coef_b = nullptr, *d_smean = nullptr, *d_sinv = nullptr;
@@ -317,9 +320,15 @@ int dan_train_finalize(dan_trainer_t* t) {
     // ---- packed weights and padded constants
     t->pk_conv_f.resize(NL); t->pk_conv_d.resize(NL); t->pk_res_f.assign(NL, nullptr); t->pk_res_d.assign(NL, nullptr);
     t->pk_bot_f.assign(NL, nullptr); t->pk_bot_d.assign(NL, nullptr);
+    t->pk_wino_f.assign(NL, nullptr); t->pk_wino_d.assign(NL, nullptr); t->wino_layer.assign(NL, 0);
+    if ((rc = talloc(t, &t->d_wino_u, (size_t)CPAD * CPAD * 4))) return rc;
     for (int l = 0; l < NL; ++l) {
         const LayerP& lp = t->layers[l];
         if ((rc = talloc(t, &t->pk_conv_f[l], (size_t)3 * lp.kg * KGC * 256)) || (rc = talloc(t, &t->pk_conv_d[l], (size_t)3 * KGC * KGC * 256))) return rc;
+        if (l > 0 && lp.dil == 2 && c.conv_algo != 1) {     // 3 taps at dilation 2 on 128-channel rows: Winograd F(2,3) form
+            t->wino_layer[l] = 1;
+            if ((rc = talloc(t, &t->pk_wino_f[l], (size_t)4 * KGC * KGC * 256)) || (rc = talloc(t, &t->pk_wino_d[l], (size_t)4 * KGC * KGC * 256))) return rc;
+        }
         if (lp.residual && ((rc = talloc(t, &t->pk_res_f[l], (size_t)KGC * KGC * 256)) || (rc = talloc(t, &t->pk_res_d[l], (size_t)KGC * KGC * 256)))) return rc;
         if (H > 0 && ((rc = talloc(t, &t->pk_bot_f[l], (size_t)KGC * 2 * 256)) || (rc = talloc(t, &t->pk_bot_d[l], (size_t)2 * KGC * 256)))) return rc;
     }
@@ -398,6 +407,13 @@ void refresh_packed(dan_trainer* t, hipStream_t s) {
         launch_pack_frag(t->pk_conv_f[l], W, 3, lp.kg, KGC, lp.cout, cin_canon, (long long)lp.cin * 3, 3, 1, 0, nullptr, cmap, s);
         // data gradient: du[p][c] = sum_{o,t'} W[o][c][2 - t'] dz[p + (t' - 1) d][o]: outputs c (canonical for layer 1), k = o
         launch_pack_frag(t->pk_conv_d[l], W, 3, KGC, KGC, cin_canon, lp.cout, 3, (long long)lp.cin * 3, 1, 1, cmap, nullptr, s);
+        if (t->wino_layer[l]) {
+            // forward: U(o, c);  data gradient: outputs c, inputs o, flipped taps
+            launch_wino_u(t->d_wino_u, W, lp.cout, lp.cin, (long long)lp.cin * 3, 3, 0, s);
+            launch_pack_frag(t->pk_wino_f[l], t->d_wino_u, 4, KGC, KGC, lp.cout, lp.cin, (long long)lp.cin * 4, 4, 1, 0, nullptr, nullptr, s);
+            launch_wino_u(t->d_wino_u, W, lp.cin, lp.cout, 3, (long long)lp.cin * 3, 1, s);
+            launch_pack_frag(t->pk_wino_d[l], t->d_wino_u, 4, KGC, KGC, lp.cin, lp.cout, (long long)lp.cout * 4, 4, 1, 0, nullptr, nullptr, s);
+        }
         float* b = t->d_bias + (size_t)l * 3 * CPAD;
         launch_pad_copy(b, pp(t, lp.conv_b), lp.cout, CPAD, s);
         if (lp.residual) {
@@ -489,6 +505,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
             if (l == 0) { a.mode = 0; fill_encode(a, t, B); }
             else { a.mode = 1; a.src1 = t->d_x[l - 1]; a.s1_stride = CPAD; a.pool_in = t->d_pool[l]; }
             a.w1 = t->pk_conv_f[l]; a.taps = 3; a.kg = lp.kg; a.dil = lp.dil;
+            if (t->wino_layer[l]) { a.w1 = t->pk_wino_f[l]; a.wino = 1; }
             a.bias1 = bias; a.relu_out = 1; a.out1 = t->d_a[l];
             a.stats = c.use_bn ? t->d_stats : nullptr;
             launch_train_row(a, n_rows, s);
@@ -638,6 +655,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
             RowArgs a{};
             a.R = R; a.L = L; a.mode = 1; a.src1 = dn; a.s1_stride = CPAD; a.src2 = t->d_a[l]; a.coef = t->d_coef_b; a.mask_src2 = 1;
             a.w1 = t->pk_conv_d[l]; a.taps = 3; a.kg = KGC; a.dil = lp.dil;
+            if (t->wino_layer[l]) { a.w1 = t->pk_wino_d[l]; a.wino = 1; }
             a.out1 = t->d_du;
             launch_train_row(a, n_rows, s);
         }

@@ -86,7 +86,11 @@ def main():
     traffic["segment_kernel_bytes_per_launch"] = {"fetch_corrected": fetch, "write": seg_bytes["WRITE_SIZE"],
                                                   "total": fetch + seg_bytes["WRITE_SIZE"]}
     n_disp = max(d["dispatches"] for k, d in traffic["per_kernel"]["WRITE_SIZE"].items() if "segment_kernel" in k)
-    R, L, S = 64, 201, 4096 * 2 // n_disp                     # the PMC bench runs 4096 sites, 2 segment launches per chunk
+    # the PMC bench runs 4096 sites, 2 segment launches per chunk -- once for the timed pass and once more when the line carries
+    # the host_path pass (same chunking)
+    pmc_line = [l for l in open(os.path.join(src, "FETCH_SIZE.json")) if l.startswith("{")]
+    passes = 2 if pmc_line and "host_path" in json.loads(pmc_line[-1]) else 1
+    R, L, S = 64, 201, 4096 * 2 * passes // n_disp
     y = S * R * L * 128 * 4
     algo = (S * (3 * R * L + 3 * L) + 3 * y + 7 * S * R * L * 32 * 4 + S * L * 128 * 4) / 2.0
     traffic["segment_kernel_algorithmic_bytes_per_launch"] = {
