@@ -124,7 +124,7 @@ def bench_train(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    cfg = DanConfig(reads=100, length=args.window)
+    cfg = DanConfig(reads=100, length=args.window, conv_algo=args.conv_algo)
     hp = TrainHyper()
     B = args.train_batch
     sd = random_state_dict(cfg, seed=0)

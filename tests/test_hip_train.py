@@ -76,6 +76,21 @@ def test_train_step_matches_reference_training_loop(case):
     tr.close()
 
 
+def test_winograd_form_of_the_training_convolutions_is_opt_in_and_passes_the_fixtures():
+    """conv_algo 2 runs the dilation-2 forward convolutions and data gradients in Winograd F(2,3) form (the inference kernel's
+    core).  Same fixtures, same 1e-4 bar; it is not the default because at production width its larger rounding noise flips
+    more ReLU masks than the direct form does."""
+    import dataclasses
+    spec, hyper, w, steps, *_ = load_train_case("train_small")
+    cfg, hp, st = dataclasses.replace(cfg_from(spec), conv_algo=2), hyper_from(hyper), steps[0]
+    tr = DanTrainer(cfg, hp, max_batch=6).load_state_dict(w)
+    out = tr.train_step(st["planes"], st["targets"], dropout_masks=st["masks"])
+    assert abs(out["loss"] - float(st["loss"])) <= LOSS_TOL * max(1.0, abs(float(st["loss"])))
+    worst = check_grads(tr, st["grad"], "train_small, winograd")
+    print("winograd form: worst gradient %s at %.2g of its max" % worst)
+    tr.close()
+
+
 def test_train_forward_activations_match_oracle():
     """Per-layer train-mode activations (BatchNorm on batch statistics) against the oracle's taps: localises a forward bug."""
     spec, hyper, w, steps, *_ = load_train_case("train_small")
