@@ -264,8 +264,189 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
     }
 }
 
-void launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
+// ------------------------------------------------------------------------------------------------
+// T1p: the POINTWISE launches (1x1 GEMMs: BN-apply [+ residual] + bottleneck, the accumulation of g_l with the bottleneck's
+// transpose, the residual's transpose).  Nothing reaches sideways, so the unit is a tile of 64 positions of the flat
+// [rows * L] position axis instead of a whole read: 35 KB of LDS and <= 128 registers, FOUR workgroups (16 waves) per CU, and
+// the HBM-bound streaming of one tile overlaps the GEMM of the others (as whole-read workgroups, one per CU, these launches
+// ran at ~55 % of the HBM rate).  Wave = 32 output channels x the 4 position tiles.  Same RowArgs, same epilogue; `stats`
+// entries are per tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int TP_POS = 64, TP_THREADS = 256, TP_MT = TP_POS / 16;
+__global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, long long n_pos) {
+    __shared__ __attribute__((aligned(16))) float xs[TP_POS * LDS_S];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long base = (long long)blockIdx.x * TP_POS;
+    const int L = a.L;
+    const int n_here = (int)min((long long)TP_POS, n_pos - base);
+    // ---- load the tile (positions beyond the tensor are zero)
+    {
+        const int vpr = a.s1_stride >> 2;
+        const v4f* s1 = (const v4f*)a.src1 + base * vpr;
+        const v4f* s2 = a.src2 ? (const v4f*)a.src2 + base * vpr : nullptr;
+        constexpr int NP = TP_POS * (CPAD / 4) / TP_THREADS;        // 8
+        v4f r1[NP], r2[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * TP_THREADS;
+            const bool ok = i < n_here * vpr;
+            r1[k] = ok ? s1[i] : splat(0.f);
+            r2[k] = (ok && s2) ? s2[i] : splat(0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * TP_THREADS;
+            if (i < TP_POS * vpr) {
+                const int pr = i / vpr, c4 = i - pr * vpr;
+                *(v4f*)(xs + pr * LDS_S + c4 * 4) = (pr < n_here) ? load_transform(r1[k], r2[k], a.coef, c4 * 4, a.mask_src2) : splat(0.f);
+            }
+        }
+        if (vpr < CPAD / 4) {                                    // 32-channel input: the GEMM reads only its kg groups, nothing to clear
+        }
+    }
+    __syncthreads();
+    const int pos = lane & 15, kk = lane >> 4;
+    const int cq = wave;
+    int chb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) chb[n] = (cq * NT + n) * 16 + kk * 4;
+    v4f acc[TP_MT][NT];
+    if (a.w1) {
+        gv4f_ptr w = (gv4f_ptr)(a.w1) + (cq * NT) * 64 + lane;
+        const float* xrow = xs + pos * LDS_S + kk * 4;
+        v4f a_nxt[NT], b[TP_MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a_nxt[n] = w[n * 64];
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m) { b[m] = *(const v4f*)(xrow + m * 16 * LDS_S); acc[m][0] = splat(0.f); acc[m][1] = splat(0.f); }
+        for (int g = 0; g < a.kg; ++g) {
+            v4f av[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) av[n] = a_nxt[n];
+            const int gn = (g + 1 < a.kg) ? g + 1 : g;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) a_nxt[n] = w[(size_t)gn * (KGC * 64) + n * 64];
+#pragma unroll
+            for (int m = 0; m < TP_MT; ++m) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(av[n][sidx], b[m][sidx], acc[m][n]);
+                b[m] = *(const v4f*)(xrow + m * 16 * LDS_S + gn * 16);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = *(const v4f*)(xs + (m * 16 + pos) * LDS_S + chb[n]);
+    }
+    // ---- epilogue (flat position q = base + m 16 + pos; its site for the per-site addend)
+    v4f s0[NT], s1v[NT], bias[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        s0[n] = splat(0.f); s1v[n] = splat(0.f);
+        bias[n] = a.bias1 ? *(const v4f*)(a.bias1 + chb[n]) : splat(0.f);
+    }
+    const long long per_site = (long long)a.R * L;
+#pragma unroll
+    for (int m = 0; m < TP_MT; ++m) {
+        const int pl = m * 16 + pos;
+        const bool live = pl < n_here;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            v4f v = splat(0.f);
+            if (live) {
+                const long long q = base + pl;
+                const size_t o = (size_t)q * CPAD + chb[n];
+                v = acc[m][n] + bias[n];
+                if (a.add1) v += *(const v4f*)(a.add1 + o);
+                if (a.add2) v += *(const v4f*)(a.add2 + o);
+                if (a.addb) {
+                    const long long site = q / per_site;
+                    const int p = (int)(q % L);
+                    v += *(const v4f*)(a.addb + ((size_t)site * L + p) * CPAD + chb[n]);
+                }
+                if (a.relu_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (a.stats) {
+                    const v4f x = a.stat_aux ? *(const v4f*)(a.stat_aux + o) : v;
+                    s0[n] += v;
+                    s1v[n] += v * x;
+                }
+                if (a.out1) *(v4f*)(a.out1 + o) = v;
+            }
+            acc[m][n] = v;
+        }
+    }
+    if (a.stats) {                                               // every channel belongs to exactly one (wave, tile, k-quarter, j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s0[n][j], y = s1v[n][j];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) { x += __shfl_xor(x, msk); y += __shfl_xor(y, msk); }
+                if (pos == 0) {
+                    a.stats[((size_t)blockIdx.x * 2 + 0) * CPAD + chb[n] + j] = x;
+                    a.stats[((size_t)blockIdx.x * 2 + 1) * CPAD + chb[n] + j] = y;
+                }
+            }
+    }
+    if (a.w2) {
+        __syncthreads();                                         // every wave has finished reading the tile
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) *(v4f*)(xs + (m * 16 + pos) * LDS_S + chb[n]) = acc[m][n];
+        // 128 -> 32 bottleneck: wave = (channel tile n = wave & 1, position tiles (wave >> 1), (wave >> 1) + 2)
+        gv4f_ptr wb = (gv4f_ptr)(a.w2) + lane;
+        const int nb = wave & 1, p0 = wave >> 1;
+        v4f wbot[KGC];
+#pragma unroll
+        for (int g = 0; g < KGC; ++g) wbot[g] = wb[(g * 2 + nb) * 64];
+        __syncthreads();
+        v4f hacc[2];
+        {
+            const v4f bb = *(const v4f*)(a.bias2 + nb * 16 + kk * 4);
+            hacc[0] = bb; hacc[1] = bb;
+        }
+        const float* xrow = xs + pos * LDS_S + kk * 4;
+#pragma unroll
+        for (int g = 0; g < KGC; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const v4f bv = *(const v4f*)(xrow + (p0 + 2 * i) * 16 * LDS_S + g * 16);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) hacc[i] = mfma16(wbot[g][sidx], bv[sidx], hacc[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pl = (p0 + 2 * i) * 16 + pos;
+            if (pl < n_here) {
+                v4f v = hacc[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
+                *(v4f*)(a.out2 + (size_t)(base + pl) * HPAD + nb * 16 + kk * 4) = v;
+            }
+        }
+    }
+}
+
+// Returns the number of `stats` entries the launch writes (reads for the whole-read form, 64-position tiles for the pointwise one).
+int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
+    const bool pointwise = a.mode == 1 && !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
+    if (pointwise) {
+        const long long n_pos = (long long)n_rows * a.L;
+        const int tiles = (int)((n_pos + TP_POS - 1) / TP_POS);
+        hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
+        return tiles;
+    }
     hipLaunchKernelGGL(train_row_kernel, dim3((unsigned)n_rows), dim3(SEG_THREADS), 0, s, a);
+    return n_rows;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -361,7 +361,8 @@ int dan_train_finalize(dan_trainer_t* t) {
         if (pool_after(c, l + 1) && (rc = talloc(t, &t->d_pool[l + 1], (size_t)B * rowf, false))) return rc;
     }
     if (H > 0 && ((rc = talloc(t, &t->d_h, (size_t)NL * rows * L * HPAD, false)) || (rc = talloc(t, &t->d_dh, (size_t)NL * rows * L * HPAD, false)))) return rc;
-    if ((rc = talloc(t, &t->d_stats, rows * 2 * CPAD)) || (rc = talloc(t, &t->d_bp, (rows / 32 + 2) * 2 * CPAD + (size_t)(t->n_flat / (256 * 64) + 2)))) return rc;
+    const size_t stat_max = std::max<size_t>(rows, (rows * L + 63) / 64);      // entries: one per read, or per 64-position tile
+    if ((rc = talloc(t, &t->d_stats, stat_max * 2 * CPAD)) || (rc = talloc(t, &t->d_bp, (stat_max / 32 + 2) * 2 * CPAD + (size_t)(t->n_flat / (256 * 64) + 2)))) return rc;
     if ((rc = talloc(t, &t->d_feat, (size_t)B * t->F_stride)) || (rc = talloc(t, &t->d_featd, (size_t)B * t->F_stride)) ||
         (rc = talloc(t, &t->d_hid0, (size_t)B * t->n0_stride)) || (rc = talloc(t, &t->d_hid0d, (size_t)B * t->n0_stride)) ||
         (rc = talloc(t, &t->d_hid1, (size_t)B * t->n1_stride)) || (rc = talloc(t, &t->d_hid1d, (size_t)B * t->n1_stride)) ||
@@ -499,6 +500,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
     HIPT(t, hipMemsetAsync(t->G, 0, (size_t)t->n_flat * sizeof(float), s));
     refresh_packed(t, s);
 
+    int stat_entries = 0;                                    // entries of d_stats the last statistics-producing launch wrote
     // =========================================== forward (train mode) ===========================================
     for (int l = 0; l < NL; ++l) {
         const LayerP& lp = t->layers[l];
@@ -513,11 +515,11 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
             if (t->wino_layer[l]) { a.w1 = t->pk_wino_f[l]; a.wino = 1; }
             a.bias1 = bias; a.relu_out = 1; a.out1 = t->d_a[l];
             a.stats = c.use_bn ? t->d_stats : nullptr;
-            launch_train_row(a, n_rows, s);
+            stat_entries = launch_train_row(a, n_rows, s);
         }
         if (c.use_bn) {                                      // batch statistics over (B, R, L) per channel (model.py:750-751, train mode)
             int nb = 0;
-            launch_stats_partial(t->d_stats, n_rows, t->d_bp, &nb, s);
+            launch_stats_partial(t->d_stats, stat_entries, t->d_bp, &nb, s);
             launch_bn_forward_finalize(t->d_bp, nb, n_pos, pp(t, lp.bn_g), pp(t, lp.bn_b), lp.cout, coef_f, t->d_smean + (size_t)l * CPAD,
                                        t->d_sinv + (size_t)l * CPAD, t->d_rmean + (size_t)l * CPAD, t->d_rvar + (size_t)l * CPAD, s);
         }
@@ -609,7 +611,8 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
             a.addb = pooled ? t->d_dpool : nullptr;
             a.out1 = g;
             if (!lp.residual) { a.stats = t->d_stats; a.stat_aux = t->d_a[l]; }
-            launch_train_row(a, n_rows, s);
+            const int e = launch_train_row(a, n_rows, s);
+            if (!lp.residual) stat_entries = e;
         }
         const float* dn = g;
         if (lp.residual) {   // x_l = W_r n_l + b_r + x_{l-1}:  dn_l = W_r^T g_l;  gW_r = g_l n_l^T;  g_{l-1} += g_l (next iteration's add2)
@@ -617,7 +620,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
             a.R = R; a.L = L; a.mode = 1; a.src1 = g; a.s1_stride = CPAD;
             a.w1 = t->pk_res_d[l]; a.taps = 1; a.kg = KGC; a.dil = 0;
             a.out1 = t->d_dn; a.stats = t->d_stats; a.stat_aux = t->d_a[l];
-            launch_train_row(a, n_rows, s);
+            stat_entries = launch_train_row(a, n_rows, s);
             dn = t->d_dn;
             WgradArgs w{};
             w.R = R; w.L = L; w.n_rows = n_rows; w.a1 = g; w.a_stride = CPAD;
@@ -628,7 +631,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
         }
         {   // BatchNorm backward coefficients from sum(dn), sum(dn * a)  (identity without BatchNorm)
             int nb = 0;
-            launch_stats_partial(t->d_stats, n_rows, t->d_bp, &nb, s);
+            launch_stats_partial(t->d_stats, stat_entries, t->d_bp, &nb, s);
             launch_bn_backward_coef(t->d_bp, nb, n_pos, pp(t, lp.bn_g), t->d_smean + (size_t)l * CPAD, t->d_sinv + (size_t)l * CPAD, lp.cout, c.use_bn,
                                     t->d_coef_b, gp(t, lp.bn_g), gp(t, lp.bn_b), s);
         }
