@@ -135,7 +135,9 @@ class DanTrainer:
             raise RuntimeError("dan_train_create failed (%d): %s" % (rc, self.lib.dan_train_last_error(None).decode()))
         self._h = h
         self._loaded = False
-        self._fc_keys = ("conv2hidden.1", "conv2hidden.4")
+        # state-dict indices of the two FC Linear layers: 1 / 4 when the model carries dropout modules, 0 / 3 when it does not
+        # (model.py:369-377); a loaded checkpoint's own indices win
+        self._fc_keys = ("conv2hidden.1", "conv2hidden.4") if hyper.dropout > 0 else ("conv2hidden.0", "conv2hidden.3")
         self._extra: Dict[str, np.ndarray] = {}
 
     def _check(self, rc, what):
