@@ -265,9 +265,10 @@ def main():
             dist.init_process_group(backend)
 
     props = torch.cuda.get_device_properties(local_rank)
-    print("[bench rank %d/%d] pid %d device cuda:%d %s, %d CUs, %.0f GiB, backend %s" %
-          (rank, world, os.getpid(), local_rank, props.name, props.multi_processor_count, props.total_memory / 2**30,
-           backend if world > 1 else "none"), file=sys.stderr, flush=True)
+    sys.stderr.write("[bench rank %d/%d] pid %d device cuda:%d %s, %d CUs, %.0f GiB, backend %s\n" %
+                     (rank, world, os.getpid(), local_rank, props.name, props.multi_processor_count, props.total_memory / 2**30,
+                      backend if world > 1 else "none"))
+    sys.stderr.flush()
 
     cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision, conv_algo=args.conv_algo,
                     skip_empty_rows=args.skip_empty_rows)
