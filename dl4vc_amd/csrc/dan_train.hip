@@ -84,9 +84,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
     const int row = blockIdx.x;
     const int site = row / a.R;
     const int L = a.L;
-    for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
-    __syncthreads();
     if (a.mode == 0) {
+        // encode writes 48 of a row's 128 channels and layer 1 reads only those: clear the whole image once
+        for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+        __syncthreads();
         EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
         encode_rows(xs, LDS_S, HALO, 0, L, e, (size_t)row, site, L, tid);
     } else {
@@ -97,6 +98,18 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
         const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
         // the whole read (and its second tensor / pool image) in flight at once, then transform + store: a loop of dependent
         // load -> LDS store round trips leaves one CU streaming at a few loads per latency
+        // (rows loaded from a 128-channel tensor cover every column the GEMMs read: only the rows the read does not cover --
+        // halo rows and rows >= L -- are cleared, disjoint from the rows stored below, so no barrier in between)
+        if (vpr < CPAD / 4) {                                    // (a narrower tensor: clear everything first)
+            for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+            __syncthreads();
+        } else {
+            for (int i = tid; i < (TR_LDS_ROWS - L) * (LDS_S / 4); i += SEG_THREADS) {
+                const int rr = i / (LDS_S / 4), c4 = i - rr * (LDS_S / 4);
+                const int zr = rr < HALO ? rr : rr + L;
+                *(v4f*)(xs + zr * LDS_S + c4 * 4) = splat(0.f);
+            }
+        }
         constexpr int NP = (MPOS * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;     // 13
         v4f r1[NP], r2[NP], r3[NP];
 #pragma unroll
