@@ -1,0 +1,19 @@
+#!/bin/bash
+# Kernel trace of the training bench (run on the GPU box from the repository root): tools/profile_train.sh r02
+# -> gpurun_out/prof_train_<tag>/kt/**/*kernel_stats.csv and a short table on stdout.
+set -eo pipefail
+tag=${1:-r02}
+out=gpurun_out/prof_train_$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+root=$PWD
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out/kt" -- python3 "$root/bench.py" --mode train --steps 5 --warmup 2 --no-cpu-baseline > "$root/$out/bench_under_rocprof.json" 2> "$root/$out/kt.log"
+cd "$root"
+python3 - "$out" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/kt/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+for r in rows[:16]:
+    print("%-58s %6s calls %12s ns total %10s ns avg %6s %%" % (r["Name"][:58], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+PY
