@@ -101,10 +101,11 @@ def bench_train(args):
     BatchNorm batch statistics and dropout, loss mix, backward, gradient clipping, Adam; dl4vc/trainer.py:109-439) on a
     synthetic batch of --train-batch sites x 100 reads x 201 bp per GPU (100 reads: the reference's dataset always yields
     MAX_READS = 100, dl4vc/dataset.py:398), production network, fp32, seeded weights.  N > 1: one process per GPU, the flat
-    gradient buffer averaged with ONE RCCL all-reduce per step (replaces nn.DataParallel, main.py:117); weak scaling."""
+    gradient buffer averaged in two buckets (dl4vc_amd.train.GradientExchange: direct reduce-scatter + all-gather over RCCL,
+    the FC-side bucket under the convolution layers' backward; replaces nn.DataParallel, main.py:117); weak scaling."""
     import torch
     from dl4vc_amd.config import DanConfig
-    from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights, average_gradients
+    from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights, GradientExchange
     from dl4vc_amd import synth
     from dl4vc_amd.synth import random_state_dict
     rank = int(os.environ.get("RANK", "0"))
@@ -137,11 +138,19 @@ def bench_train(args):
     tg["weight"] = example_weights(tg["is_snp"], hp)
     planes = batch.arrays()
     grad = tr.grad_tensor() if world > 1 else None
+    exchange = GradientExchange(dist, world) if world > 1 else None
+    (o0, n0), (o1, n1) = tr.grad_buckets()
 
     def step(i):
-        out = tr.backward(planes, tg, seed=i)
         if world > 1:
-            average_gradients(grad, world, dist.all_reduce)
+            tr.backward_begin(planes, tg, seed=i)
+            tr.wait_bucket(0)
+            exchange.start(grad[o0:o0 + n0])                  # FC stack + heads: exchanged under the conv layers' backward
+            out = tr.backward_end()
+            exchange.start(grad[o1:o1 + n1])
+            exchange.finish()
+        else:
+            out = tr.backward(planes, tg, seed=i)
         tr.apply()
         return out
 
@@ -177,7 +186,9 @@ def bench_train(args):
                 "config": {"workload": "one optimisation step (train-mode forward, focal + aux losses, backward, clip, Adam) on %d sites "
                                        "x 100 reads x %d bp per GPU, DAN production network, seeded random weights" % (B, cfg.length),
                            "sites_per_gpu_per_step": B, "reads": 100, "window": cfg.length,
-                           "parallelism": "data-parallel x%d, one all-reduce of %d gradient floats per step" % (world, tr.query("num_param_floats")),
+                           "parallelism": "data-parallel x%d, %d gradient floats averaged per step in two buckets (%s)" % (
+                               world, tr.query("num_param_floats"),
+                               "no exchange at N=1" if world == 1 else ("direct reduce-scatter + all-gather" if exchange.direct else "all-reduce")),
                            "gflop_per_site": round(flops_site / 1e9, 3)},
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,

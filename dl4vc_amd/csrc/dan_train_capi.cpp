@@ -100,6 +100,9 @@ struct dan_trainer {
     long long split_ws_floats = 0;
     double* d_emb_bp = nullptr;
     int last_B = 0;
+    // dan_train_backward_begin / _end: the step in flight and the event behind which the FC-side gradients are final
+    bool pending = false;
+    hipEvent_t ev_tail = nullptr;
 };
 
 namespace {
@@ -384,6 +387,7 @@ int dan_train_finalize(dan_trainer_t* t) {
     t->split_ws_floats = (long long)32 * B * std::max(t->n0, t->n1);
     if ((rc = talloc(t, &t->d_split_ws, (size_t)t->split_ws_floats, false))) return rc;
     HIPT(t, hipDeviceSynchronize());
+    HIPT(t, hipEventCreateWithFlags(&t->ev_tail, hipEventDisableTiming));
     t->finalized = true;
     return DAN_OK;
 }
@@ -393,6 +397,7 @@ void dan_train_destroy(dan_trainer_t* t) {
     (void)hipSetDevice(t->cfg.device_id);
     (void)hipDeviceSynchronize();
     for (void* p : t->allocs) (void)hipFree(p);
+    if (t->ev_tail) (void)hipEventDestroy(t->ev_tail);
     delete t;
 }
 
@@ -451,11 +456,12 @@ void fill_encode(RowArgs& a, const dan_trainer* t, int B) {
 
 extern "C" {
 
-int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
-                       const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, const dan_train_targets* tg,
-                       const uint8_t* const* dropout_masks, uint64_t seed, float* losses, uint8_t* close) {
+int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
+                             const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, const dan_train_targets* tg,
+                             const uint8_t* const* dropout_masks, uint64_t seed) {
     if (!t) return DAN_ERR_INVALID_ARG;
     if (!t->finalized) return failt(t, DAN_ERR_STATE, "dan_train_backward before dan_train_finalize");
+    if (t->pending) return failt(t, DAN_ERR_STATE, "dan_train_backward_begin: the previous step has not been ended (dan_train_backward_end)");
     if (n_sites < 1 || n_sites > t->max_batch) return failt(t, DAN_ERR_INVALID_ARG, "a training batch holds 1..%d sites, got %lld", t->max_batch, (long long)n_sites);
     if (!reads || !qual || !strand || !ref || !ref_mask || !var_mask) return failt(t, DAN_ERR_INVALID_ARG, "null input plane");
     if (!tg || !tg->label || !tg->var_type || !tg->allele_freq || !tg->coverage || !tg->var_base_enum || !tg->var_ref_enum || !tg->weight)
@@ -567,6 +573,7 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
     // FC1
     launch_gemm(t->d_dhid0, t->n0_stride, 1, t->d_featd, t->F_stride, 1, nullptr, gp(t, t->p_fc0w), t->F_stride, t->n0, t->F, B, 0, t->d_split_ws, t->split_ws_floats, s);
     launch_colsum(t->d_dhid0, B, t->n0, t->n0_stride, gp(t, t->p_fc0b), s);
+    HIPT(t, hipEventRecord(t->ev_tail, s));                  // bucket 0 (FC stack + heads: the tail of the flat buffer) is final
     launch_gemm(t->d_dhid0, t->n0_stride, 0, pp(t, t->p_fc0w), t->F_stride, 1, nullptr, t->d_dfeatd, t->F_stride, B, t->F, t->n0, 0, t->d_split_ws, t->split_ws_floats, s);
     launch_dropout_relu_bwd(t->d_dfeatd, mk[0], dscale, nullptr, 0, t->d_dfeat, B, t->F, t->F_stride, s);
     // highway compression
@@ -676,15 +683,52 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
         launch_embedding_grad(t->d_du, e.reads, e.ref, B, R, L, t->d_emb_partial, t->d_emb_bp, gp(t, t->p_emb), s);
     }
     HIPT(t, hipGetLastError());
-    HIPT(t, hipDeviceSynchronize());
+    t->pending = true;
+    return DAN_OK;
+}
+
+int dan_train_backward_end(dan_trainer_t* t, float* losses, uint8_t* close) {
+    if (!t) return DAN_ERR_INVALID_ARG;
+    if (!t->pending) return failt(t, DAN_ERR_STATE, "dan_train_backward_end without dan_train_backward_begin");
+    HIPT(t, hipSetDevice(t->cfg.device_id));
+    t->pending = false;
+    HIPT(t, hipStreamSynchronize(nullptr));
     if (losses) HIPT(t, hipMemcpy(losses, t->d_losses, 7 * sizeof(float), hipMemcpyDeviceToHost));
-    if (close) HIPT(t, hipMemcpy(close, t->d_close, (size_t)B * 2, hipMemcpyDeviceToHost));
+    if (close) HIPT(t, hipMemcpy(close, t->d_close, (size_t)t->last_B * 2, hipMemcpyDeviceToHost));
+    return DAN_OK;
+}
+
+int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
+                       const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, const dan_train_targets* tg,
+                       const uint8_t* const* dropout_masks, uint64_t seed, float* losses, uint8_t* close) {
+    const int rc = dan_train_backward_begin(t, reads, qual, strand, ref, ref_mask, var_mask, n_sites, tg, dropout_masks, seed);
+    if (rc) return rc;
+    return dan_train_backward_end(t, losses, close);
+}
+
+int dan_train_grad_bucket(dan_trainer_t* t, int32_t bucket, int64_t* offset, int64_t* count) {
+    if (!t || !t->finalized) return DAN_ERR_STATE;
+    if (bucket < 0 || bucket > 1) return failt(t, DAN_ERR_INVALID_ARG, "gradient buckets are 0 (FC stack + heads) and 1 (everything before them)");
+    const int64_t cut = t->params[t->p_fc0w].off;
+    if (offset) *offset = bucket == 0 ? cut : 0;
+    if (count) *count = bucket == 0 ? t->n_flat - cut : cut;
+    return DAN_OK;
+}
+
+int dan_train_wait_bucket(dan_trainer_t* t, int32_t bucket) {
+    if (!t) return DAN_ERR_INVALID_ARG;
+    if (!t->pending) return failt(t, DAN_ERR_STATE, "dan_train_wait_bucket: no step in flight");
+    if (bucket < 0 || bucket > 1) return failt(t, DAN_ERR_INVALID_ARG, "gradient buckets are 0 and 1");
+    HIPT(t, hipSetDevice(t->cfg.device_id));
+    if (bucket == 0) HIPT(t, hipEventSynchronize(t->ev_tail));
+    else HIPT(t, hipStreamSynchronize(nullptr));
     return DAN_OK;
 }
 
 int dan_train_apply(dan_trainer_t* t, float* grad_norm) {
     if (!t) return DAN_ERR_INVALID_ARG;
     if (!t->finalized) return failt(t, DAN_ERR_STATE, "dan_train_apply before dan_train_finalize");
+    if (t->pending) return failt(t, DAN_ERR_STATE, "dan_train_apply with a step in flight: call dan_train_backward_end first");
     HIPT(t, hipSetDevice(t->cfg.device_id));
     hipStream_t s = nullptr;
     const dan_train_hyper& hp = t->hp;

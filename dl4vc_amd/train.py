@@ -22,7 +22,8 @@ from .model import normalise_state_dict
 
 TRAIN_SYMBOLS = ("dan_train_create", "dan_train_set_tensor", "dan_train_finalize", "dan_train_destroy", "dan_train_last_error",
                  "dan_train_backward", "dan_train_apply", "dan_train_step", "dan_train_set_lr", "dan_train_grad_buffer", "dan_train_get_tensor",
-                 "dan_train_put_tensor", "dan_train_query")
+                 "dan_train_put_tensor", "dan_train_query", "dan_train_backward_begin", "dan_train_backward_end", "dan_train_wait_bucket",
+                 "dan_train_grad_bucket")
 
 LOSS_NAMES = ("loss", "bin", "vt", "af", "cov", "vb", "vr")
 
@@ -81,6 +82,10 @@ def _bind(lib):
     lib.dan_train_last_error.restype = C.c_char_p
     planes = [vp] * 6
     lib.dan_train_backward.argtypes = [vp] + planes + [C.c_int64, C.POINTER(_CTargets), C.POINTER(vp), C.c_uint64, vp, vp]
+    lib.dan_train_backward_begin.argtypes = [vp] + planes + [C.c_int64, C.POINTER(_CTargets), C.POINTER(vp), C.c_uint64]
+    lib.dan_train_backward_end.argtypes = [vp, vp, vp]
+    lib.dan_train_wait_bucket.argtypes = [vp, C.c_int32]
+    lib.dan_train_grad_bucket.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.dan_train_apply.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dan_train_step.argtypes = [vp] + planes + [C.c_int64, C.POINTER(_CTargets), C.POINTER(vp), C.c_uint64, vp, vp, C.POINTER(C.c_float)]
     lib.dan_train_set_lr.argtypes = [vp, C.c_float]
@@ -113,6 +118,60 @@ def average_gradients(grad, world_size: int, all_reduce) -> None:
         return
     all_reduce(grad)
     grad *= 1.0 / world_size
+
+
+class GradientExchange:
+    """The data-parallel gradient average of one step, bucket by bucket (replaces nn.DataParallel's
+    reduce-add, main.py:117).  ``start(bucket)`` begins averaging one window of the flat gradient buffer whose contents are
+    final; ``finish()`` returns when every started bucket holds the mean.  On the GPU the collectives and the shard sums run
+    on a side stream, so a bucket started in the middle of the backward pass (``DanTrainer.wait_bucket``) is exchanged
+    under the rest of it.
+
+    ``direct`` (the default on RCCL): reduce-scatter and all-gather in their DIRECT form -- all-to-all of the 1/world
+    chunks (every rank sends chunk j straight to rank j: on MI355X all 7 xGMI links of a GPU carry 1/8 of the bucket at
+    once, where a ring moves 2 x 7/8 of it over one link), the shard summed in rank order (the same bits on every rank),
+    then an all-gather of the shards.  Otherwise (gloo rehearsals, world sizes that do not divide a tail) a plain
+    all-reduce."""
+
+    def __init__(self, dist, world_size: int, direct=None):
+        self.dist, self.world = dist, int(world_size)
+        self.direct = (dist is not None and self.world > 1 and dist.get_backend() == "nccl") if direct is None else bool(direct)
+        self._side = None
+        self._recv: Dict[tuple, object] = {}
+
+    def start(self, bucket) -> None:
+        if self.world <= 1 or bucket.numel() == 0:
+            return
+        if bucket.is_cuda:
+            import torch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=bucket.device)
+            with torch.cuda.stream(self._side):
+                self._mean(bucket)
+        else:
+            self._mean(bucket)
+
+    def _mean(self, b) -> None:
+        import torch
+        w, n = self.world, b.numel()
+        m = n // w * w if self.direct else 0
+        if m:
+            key = (b.data_ptr(), m)
+            if key not in self._recv:
+                self._recv[key] = torch.empty(m, dtype=b.dtype, device=b.device)
+            recv = self._recv[key]
+            self.dist.all_to_all_single(recv, b[:m])
+            shard = recv.view(w, m // w).sum(0)
+            shard *= 1.0 / w
+            self.dist.all_gather_into_tensor(b[:m], shard)
+        if n > m:
+            tail = b[m:]
+            self.dist.all_reduce(tail)
+            tail *= 1.0 / w
+
+    def finish(self) -> None:
+        if self._side is not None:
+            self._side.synchronize()
 
 
 class _DevBuf:
@@ -179,7 +238,7 @@ class DanTrainer:
         return self
 
     # ---- one step -----------------------------------------------------------------------------------------------
-    def _call(self, fn, planes, targets, dropout_masks, seed, with_norm):
+    def _marshal(self, planes, targets, dropout_masks):
         reads = np.ascontiguousarray(planes[0], np.uint8)
         B = reads.shape[0]
         R, L = self.config.reads, self.config.length
@@ -210,19 +269,54 @@ class DanTrainer:
                 keep.append(m)
                 arr[i] = m.ctypes.data
             mp = arr
-        losses = np.zeros(7, np.float32)
-        close = np.zeros((B, 2), np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-        args = [self._h] + [p(a) for a in ins] + [B, C.byref(ct), mp, C.c_uint64(seed), p(losses), p(close)]
-        norm = C.c_float(0.0)
-        if with_norm:
-            args.append(C.byref(norm))
-        self._check(fn(*args), fn.__name__)
+        return B, [p(a) for a in ins] + [B, C.byref(ct), mp], (ins, tg, ct, keep)
+
+    @staticmethod
+    def _outputs(losses, close, norm=None):
         out = {k: float(v) for k, v in zip(LOSS_NAMES, losses)}
         out["bin_close"] = close[:, 0].astype(bool)
         out["vt_close"] = close[:, 1].astype(bool)
-        if with_norm:
+        if norm is not None:
             out["grad_norm"] = float(norm.value)
+        return out
+
+    def _call(self, fn, planes, targets, dropout_masks, seed, with_norm):
+        B, head, _alive = self._marshal(planes, targets, dropout_masks)
+        losses = np.zeros(7, np.float32)
+        close = np.zeros((B, 2), np.uint8)
+        args = [self._h] + head + [C.c_uint64(seed), losses.ctypes.data_as(C.c_void_p), close.ctypes.data_as(C.c_void_p)]
+        norm = C.c_float(0.0) if with_norm else None
+        if with_norm:
+            args.append(C.byref(norm))
+        self._check(fn(*args), fn.__name__)
+        return self._outputs(losses, close, norm)
+
+    # ---- the same step in two halves (``GradientExchange`` runs between them) --------------------------------------
+    def backward_begin(self, planes: Sequence, targets: Mapping, dropout_masks=None, seed: int = 0) -> None:
+        """Stage the inputs and enqueue forward + backward; returns while the device works."""
+        B, head, _alive = self._marshal(planes, targets, dropout_masks)      # (the inputs are copied before the call returns)
+        self._check(self.lib.dan_train_backward_begin(*([self._h] + head + [C.c_uint64(seed)])), "dan_train_backward_begin")
+        self._pending_B = B
+
+    def wait_bucket(self, bucket: int) -> None:
+        """Block until the gradients of ``bucket`` are final (0: FC stack + heads, produced first; 1: everything else)."""
+        self._check(self.lib.dan_train_wait_bucket(self._h, int(bucket)), "dan_train_wait_bucket")
+
+    def backward_end(self) -> Dict[str, object]:
+        losses = np.zeros(7, np.float32)
+        close = np.zeros((self._pending_B, 2), np.uint8)
+        self._check(self.lib.dan_train_backward_end(self._h, losses.ctypes.data_as(C.c_void_p), close.ctypes.data_as(C.c_void_p)),
+                    "dan_train_backward_end")
+        return self._outputs(losses, close)
+
+    def grad_buckets(self):
+        """[(offset, count)] of bucket 0 and bucket 1 in the flat gradient buffer (``grad_tensor``): together they tile it."""
+        out = []
+        for b in (0, 1):
+            off, n = C.c_int64(0), C.c_int64(0)
+            self._check(self.lib.dan_train_grad_bucket(self._h, b, C.byref(off), C.byref(n)), "dan_train_grad_bucket")
+            out.append((int(off.value), int(n.value)))
         return out
 
     def backward(self, planes: Sequence, targets: Mapping, dropout_masks=None, seed: int = 0) -> Dict[str, object]:

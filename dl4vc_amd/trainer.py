@@ -23,7 +23,7 @@ import numpy as np
 
 from .hdf5io import CandidateFile
 from .train_data import assemble_training_batch, EasyExampleSampler
-from .train import TrainHyper, average_gradients
+from .train import TrainHyper, average_gradients, GradientExchange
 
 COVERAGE_SCALE_FACTOR = 1.0 / 100.0                       # trainer.py:61
 BASE_CLASS_WEIGHT = np.array([0.001, 1., 1., 1., 1., 1., 0.001, 0.001, 1., 0.001])     # trainer.py:312-313
@@ -103,9 +103,13 @@ def split_batch(n: int, rank: int, world: int):
 
 def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyper: TrainHyper, batch_size: int, epoch: int,
                 reads_seed: int = 0, max_batches: int = 0, keep_candidate_af: bool = True, log: Optional[Callable] = print,
-                rank: int = 0, world: int = 1, all_reduce=None, gather=None, log_interval: int = 1) -> Dict[str, float]:
+                rank: int = 0, world: int = 1, all_reduce=None, gather=None, log_interval: int = 1,
+                exchange: Optional[GradientExchange] = None) -> Dict[str, float]:
     """One pass of ``trainer.train`` (trainer.py:64-472).  ``trainer``: anything with ``backward`` / ``apply`` (and
-    ``grad_tensor`` when ``world > 1``) -- ``DanTrainer`` on the GPU.  Returns the epoch's mean losses."""
+    ``grad_tensor`` when ``world > 1``) -- ``DanTrainer`` on the GPU.  With ``exchange`` (and a trainer that has the
+    ``backward_begin`` / ``wait_bucket`` / ``backward_end`` split) the FC-side gradient bucket is averaged while the
+    convolution layers' backward still runs; otherwise one ``all_reduce`` of the flat buffer after the backward pass.
+    Returns the epoch's mean losses."""
     order = sampler.epoch()
     cfg = trainer.config
     tot = {k: 0.0 for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}
@@ -122,9 +126,19 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
         batch = assemble_training_batch(read_indices(source, mine), mine, cfg.reads, seed=reads_seed,
                                         non_snp_train_weight=hyper.non_snp_train_weight, keep_candidate_af=keep_candidate_af,
                                         use_q=cfg.use_q, use_strand=cfg.use_strand)
-        out = trainer.backward(batch.planes(), batch.targets, seed=reads_seed + epoch)
-        if world > 1:
-            average_gradients(trainer.grad_tensor(), world, all_reduce)
+        if world > 1 and exchange is not None and hasattr(trainer, "backward_begin"):
+            trainer.backward_begin(batch.planes(), batch.targets, seed=reads_seed + epoch)
+            grad = trainer.grad_tensor()
+            (o0, n0), (o1, n1) = trainer.grad_buckets()
+            trainer.wait_bucket(0)
+            exchange.start(grad[o0:o0 + n0])
+            out = trainer.backward_end()
+            exchange.start(grad[o1:o1 + n1])
+            exchange.finish()
+        else:
+            out = trainer.backward(batch.planes(), batch.targets, seed=reads_seed + epoch)
+            if world > 1:
+                average_gradients(trainer.grad_tensor(), world, all_reduce)
         trainer.apply()
         flags = [(mine, out["vt_close"], batch.blacklist)]
         if world > 1 and gather is not None:

@@ -73,6 +73,20 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
                        const uint8_t* ref, const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites,
                        const dan_train_targets* targets, const uint8_t* const* dropout_masks, uint64_t seed,
                        float* losses, uint8_t* close);
+/* The same step in two halves, for the data-parallel exchange to overlap the backward pass: _begin stages the inputs and
+ * ENQUEUES the whole forward + backward (it returns while the device works); _end waits for it and copies the outputs.
+ * In between, dan_train_wait_bucket(t, 0) returns as soon as the gradients of bucket 0 are final -- the FC stack and the
+ * heads, 87 % of the 311-MB buffer at the published sizes, which the backward pass produces FIRST -- so that their
+ * all-reduce runs under the convolution layers' backward (nn.DataParallel reduces after the whole backward, main.py:117);
+ * bucket 1 (embedding, convolution / BatchNorm / residual / bottleneck / compression layers) is final at _end.
+ * dan_train_grad_bucket gives each bucket's window of dan_train_grad_buffer; the two windows tile it. */
+int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand,
+                             const uint8_t* ref, const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites,
+                             const dan_train_targets* targets, const uint8_t* const* dropout_masks, uint64_t seed);
+int dan_train_wait_bucket(dan_trainer_t* t, int32_t bucket);
+int dan_train_backward_end(dan_trainer_t* t, float* losses, uint8_t* close);
+int dan_train_grad_bucket(dan_trainer_t* t, int32_t bucket, int64_t* offset, int64_t* count);
+
 /* clip_grad_norm_ + Adam on the gradients currently on the device; advances the step counter.  grad_norm (may be NULL)
  * receives the total 2-norm before clipping. */
 int dan_train_apply(dan_trainer_t* t, float* grad_norm);

@@ -85,7 +85,7 @@ def train_main(args, argv) -> int:
         if any(rcs):
             raise SystemExit("training rank failed: %s" % rcs)
         return 0
-    dist = all_reduce = gather = None
+    dist = all_reduce = gather = exchange = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -93,6 +93,8 @@ def train_main(args, argv) -> int:
         torch.cuda.set_device(0)
         dist.init_process_group(backend, rank=rank, world_size=world)
         all_reduce = dist.all_reduce
+        from dl4vc_amd.train import GradientExchange
+        exchange = GradientExchange(dist, world)                     # bucketed, overlapped with the backward pass
 
         def gather(item):
             out = [None] * world
@@ -124,7 +126,7 @@ def train_main(args, argv) -> int:
             print("Train Epoch: %d lr: [%s] on %d GPUs!" % (epoch, trainer.hyper.lr, world))
             train_epoch(trainer, train_src, sampler, hyper, args.batch_size, epoch, reads_seed=args.reads_seed,
                         max_batches=args.max_train_batches, keep_candidate_af=args.aux_keep_candidate_af, rank=rank, world=world,
-                        all_reduce=all_reduce, gather=gather, log_interval=args.log_interval,
+                        all_reduce=all_reduce, gather=gather, exchange=exchange, log_interval=args.log_interval,
                         log=lambda m: print(m, end="\r"))
             print("\n\tTime elapsed for training {:.4f}\n".format(time.time() - s), flush=True)
             s_eval = time.time()

@@ -196,3 +196,43 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     assert last < 0.6 * first, (first, last)
     assert tr.query("step") == 40
     tr.close()
+
+
+def test_split_step_and_gradient_buckets():
+    """dan_train_backward_begin / _wait_bucket / _end: the same step as dan_train_backward bit for bit; the two bucket windows
+    tile the flat gradient buffer, bucket 0 is the FC stack + heads, and it is already final when wait_bucket(0) returns
+    (that is what lets its exchange run under the rest of the backward pass)."""
+    import torch
+    spec, hyper, w, steps, *_ = load_train_case("train_small")
+    cfg, hp, st = cfg_from(spec), hyper_from(hyper), steps[0]
+    tr = DanTrainer(cfg, hp, max_batch=6).load_state_dict(w)
+    ref = tr.backward(st["planes"], st["targets"], dropout_masks=st["masks"])
+    g = tr.grad_tensor()
+    whole = g.clone()
+    (o0, n0), (o1, n1) = tr.grad_buckets()
+    assert o1 == 0 and o0 == n1 and n0 + n1 == g.numel() == tr.query("num_param_floats")
+    fc0 = tr.tensor("grad:fc.0.weight")
+    assert n0 >= fc0.size and torch.equal(g[o0:o0 + 8].cpu(), torch.from_numpy(fc0.reshape(-1)[:8].copy()))
+    g.zero_()
+    tr.backward_begin(st["planes"], st["targets"], dropout_masks=st["masks"])
+    with pytest.raises(RuntimeError, match="in flight"):
+        tr.apply()
+    tr.wait_bucket(0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                         # (the default stream would queue behind the backward pass)
+        early = g[o0:o0 + n0].clone()
+    side.synchronize()
+    out = tr.backward_end()
+    assert torch.equal(early, whole[o0:o0 + n0]), "bucket 0 was not final at wait_bucket(0)"
+    assert torch.equal(g, whole)
+    assert out["loss"] == ref["loss"] and np.array_equal(out["vt_close"], ref["vt_close"])
+    with pytest.raises(RuntimeError, match="without dan_train_backward_begin"):
+        tr.backward_end()
+    with pytest.raises(RuntimeError, match="no step in flight"):
+        tr.wait_bucket(0)
+    tr.backward_begin(st["planes"], st["targets"], dropout_masks=st["masks"])
+    with pytest.raises(RuntimeError, match="has not been ended"):
+        tr.backward_begin(st["planes"], st["targets"], dropout_masks=st["masks"])
+    tr.backward_end()
+    tr.apply()
+    tr.close()

@@ -89,6 +89,49 @@ def test_data_parallel_gradient_average_world2_gloo():
     assert g.tolist() == [1, 1, 1]
 
 
+def _rank_exchange(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from dl4vc_amd.train import GradientExchange
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for direct in (True, False):
+        g = (torch.arange(17, dtype=torch.float32) + 1) * (rank + 1) ** 2      # this rank's flat gradient buffer
+        ex = GradientExchange(dist, world, direct=direct)
+        ex.start(g[6:])                                             # bucket 0: the tail (11 floats: 9 exchanged directly + 2 left over)
+        ex.start(g[:6])                                             # bucket 1
+        ex.finish()
+        out[direct] = g.tolist()
+    assert GradientExchange(dist, world).direct is False            # gloo: plain all-reduce unless asked
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_buckets_direct_and_allreduce_world3_gloo():
+    """The bucketed exchange: direct reduce-scatter (all-to-all of 1/world chunks + rank-ordered shard
+    sum) + all-gather, with the remainder that world does not divide all-reduced, equals the plain all-reduce mean, and
+    every rank ends with the same bits."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31600 + (os.getpid() % 2000)
+    world = 3
+    ps = [ctx.Process(target=_rank_exchange, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want = ((np.arange(17) + 1) * (1 + 4 + 9) / 3.0).astype(np.float32)
+    for r in range(world):
+        for direct in (True, False):
+            assert np.allclose(got[r][direct], want, rtol=1e-6), (r, direct)
+        assert got[r][True] == got[0][True]                         # rank-ordered shard sums: identical on every rank
+
+
 # ------------------------------------------------------------------------------------------------
 # the epoch harness on CPU, driven by a test double whose step is the training oracle
 # ------------------------------------------------------------------------------------------------
