@@ -22,7 +22,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 
 from .hdf5io import CandidateFile
-from .train_data import assemble_training_batch, EasyExampleSampler
+from .train_data import assemble_training_batch, read_indices, BatchPrefetcher, EasyExampleSampler   # noqa: F401
 from .train import TrainHyper, average_gradients, GradientExchange
 
 COVERAGE_SCALE_FACTOR = 1.0 / 100.0                       # trainer.py:61
@@ -77,23 +77,6 @@ def eval_losses(out: Dict[str, np.ndarray], targets: Dict[str, np.ndarray], hp: 
 
 
 # ------------------------------------------------------------------------------------------------
-def read_indices(source: CandidateFile, indices: np.ndarray) -> np.ndarray:
-    """Records at arbitrary (shuffled) indices: sorted, read in runs of consecutive indices, returned in request order."""
-    indices = np.asarray(indices, np.int64)
-    order = np.argsort(indices, kind="stable")
-    srt = indices[order]
-    out = np.empty(len(indices), dtype=source.dtype)
-    i = 0
-    while i < len(srt):
-        j = i
-        while j + 1 < len(srt) and srt[j + 1] - srt[j] <= 1:
-            j += 1
-        block = source.read(int(srt[i]), int(srt[j]) + 1)
-        out[order[i:j + 1]] = block[srt[i:j + 1] - srt[i]]
-        i = j + 1
-    return out
-
-
 def split_batch(n: int, rank: int, world: int):
     """The slice of a batch of ``n`` sites that ``nn.DataParallel``'s scatter (torch.chunk along dim 0) gives replica ``rank``."""
     chunk = -(-n // world)
@@ -104,39 +87,57 @@ def split_batch(n: int, rank: int, world: int):
 def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyper: TrainHyper, batch_size: int, epoch: int,
                 reads_seed: int = 0, max_batches: int = 0, keep_candidate_af: bool = True, log: Optional[Callable] = print,
                 rank: int = 0, world: int = 1, all_reduce=None, gather=None, log_interval: int = 1,
-                exchange: Optional[GradientExchange] = None) -> Dict[str, float]:
+                exchange: Optional[GradientExchange] = None, prefetcher: Optional[BatchPrefetcher] = None) -> Dict[str, float]:
     """One pass of ``trainer.train`` (trainer.py:64-472).  ``trainer``: anything with ``backward`` / ``apply`` (and
     ``grad_tensor`` when ``world > 1``) -- ``DanTrainer`` on the GPU.  With ``exchange`` (and a trainer that has the
     ``backward_begin`` / ``wait_bucket`` / ``backward_end`` split) the FC-side gradient bucket is averaged while the
     convolution layers' backward still runs; otherwise one ``all_reduce`` of the flat buffer after the backward pass.
-    Returns the epoch's mean losses."""
+    ``prefetcher``: loader workers assembling this rank's batches ahead of the GPU (``--num-data-workers``); without it the
+    batches are assembled in this process between steps.  Returns the epoch's mean losses."""
     order = sampler.epoch()
     cfg = trainer.config
     tot = {k: 0.0 for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}
     n_batches = close_n = items = 0
     t0 = time.perf_counter()
+    plan = []                                                          # (batch number, offset in the order, this rank's indices)
     for b, lo in enumerate(range(0, len(order), batch_size)):
         if max_batches > 0 and b > max_batches:                       # trainer.py:113-115 (same off-by-one)
             break
         idx = order[lo:lo + batch_size]
         a, e = split_batch(len(idx), rank, world)
-        mine = idx[a:e]
-        if len(mine) == 0:
+        if e <= a:
             raise RuntimeError("batch of %d sites leaves rank %d of %d without work: lower --gpus or raise --batch-size" % (len(idx), rank, world))
-        batch = assemble_training_batch(read_indices(source, mine), mine, cfg.reads, seed=reads_seed,
-                                        non_snp_train_weight=hyper.non_snp_train_weight, keep_candidate_af=keep_candidate_af,
-                                        use_q=cfg.use_q, use_strand=cfg.use_strand)
-        if world > 1 and exchange is not None and hasattr(trainer, "backward_begin"):
+        plan.append((b, lo, idx[a:e]))
+    kwargs = dict(max_reads=cfg.reads, seed=reads_seed, non_snp_train_weight=hyper.non_snp_train_weight,
+                  keep_candidate_af=keep_candidate_af, use_q=cfg.use_q, use_strand=cfg.use_strand)
+    if prefetcher is not None:
+        stream = prefetcher.batches((m for _, _, m in plan), **kwargs)
+    else:
+        stream = (assemble_training_batch(read_indices(source, m), m, **kwargs) for _, _, m in plan)
+    split = hasattr(trainer, "backward_begin")
+    feed = zip(plan, stream)
+    nxt = next(feed, None)
+    while nxt is not None:
+        (b, lo, mine), batch = nxt
+        if split:
+            # enqueue the step, then take delivery of the next batch (worker hand-over, unpickling) while the device works
             trainer.backward_begin(batch.planes(), batch.targets, seed=reads_seed + epoch)
-            grad = trainer.grad_tensor()
-            (o0, n0), (o1, n1) = trainer.grad_buckets()
-            trainer.wait_bucket(0)
-            exchange.start(grad[o0:o0 + n0])
-            out = trainer.backward_end()
-            exchange.start(grad[o1:o1 + n1])
-            exchange.finish()
+            nxt = next(feed, None)
+            if world > 1 and exchange is not None:
+                grad = trainer.grad_tensor()
+                (o0, n0), (o1, n1) = trainer.grad_buckets()
+                trainer.wait_bucket(0)
+                exchange.start(grad[o0:o0 + n0])
+                out = trainer.backward_end()
+                exchange.start(grad[o1:o1 + n1])
+                exchange.finish()
+            else:
+                out = trainer.backward_end()
+                if world > 1:
+                    average_gradients(trainer.grad_tensor(), world, all_reduce)
         else:
             out = trainer.backward(batch.planes(), batch.targets, seed=reads_seed + epoch)
+            nxt = next(feed, None)
             if world > 1:
                 average_gradients(trainer.grad_tensor(), world, all_reduce)
         trainer.apply()
@@ -164,19 +165,26 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
 
 
 def evaluate(net, source: CandidateFile, hyper: TrainHyper, batch_size: int, write: Optional[Callable[[str], None]] = None,
-             reads_seed: int = 0, max_batches: int = 0, indices: Optional[np.ndarray] = None) -> float:
+             reads_seed: int = 0, max_batches: int = 0, indices: Optional[np.ndarray] = None,
+             prefetcher: Optional[BatchPrefetcher] = None) -> float:
     """Eval-mode pass over the test file (trainer.py:509-681): mean over batches of the loss mix; optionally the scored VCF
     records.  ``net``: a ``DanNet`` (running BatchNorm statistics, no dropout)."""
     from .vcf import scored_record
     cfg = net.config
     idx_all = np.arange(len(source)) if indices is None else np.asarray(indices)
     total, n_batches = 0.0, 0
+    plan = []
     for b, lo in enumerate(range(0, len(idx_all), batch_size)):
         if max_batches > 0 and b > max_batches:                       # trainer.py:513-515
             break
-        idx = idx_all[lo:lo + batch_size]
-        batch = assemble_training_batch(read_indices(source, idx), idx, cfg.reads, seed=reads_seed,
-                                        non_snp_train_weight=hyper.non_snp_train_weight, use_q=cfg.use_q, use_strand=cfg.use_strand)
+        plan.append(idx_all[lo:lo + batch_size])
+    kwargs = dict(max_reads=cfg.reads, seed=reads_seed, non_snp_train_weight=hyper.non_snp_train_weight, use_q=cfg.use_q,
+                  use_strand=cfg.use_strand)
+    if prefetcher is not None:
+        stream = prefetcher.batches(iter(plan), **kwargs)
+    else:
+        stream = (assemble_training_batch(read_indices(source, idx), idx, **kwargs) for idx in plan)
+    for batch in stream:
         out = net.forward_u8(*batch.planes(), aux=True)
         total += eval_losses(out, batch.targets, hyper)["loss"]
         n_batches += 1

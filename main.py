@@ -112,7 +112,11 @@ def train_main(args, argv) -> int:
     else:
         trainer.load_state_dict(synth.torch_default_init(cfg, seed=args.seed, dropout_keys=hyper.dropout > 0))
     best_loss = None
-    with CandidateFile(args.train_file) as train_src, CandidateFile(args.test_file) as test_src:
+    from dl4vc_amd.train_data import BatchPrefetcher
+    # loader workers (main.py:59-60: DataLoader(num_workers=args.num_data_workers)); 0 = assemble in this process
+    with CandidateFile(args.train_file) as train_src, CandidateFile(args.test_file) as test_src, \
+            BatchPrefetcher(args.train_file, args.num_data_workers) as train_loader, \
+            BatchPrefetcher(args.test_file, args.num_data_workers if rank == 0 else 0) as test_loader:
         holdout = None
         if args.train_holdout_chromosomes:
             holdout = np.zeros(len(train_src), bool)
@@ -126,7 +130,8 @@ def train_main(args, argv) -> int:
             print("Train Epoch: %d lr: [%s] on %d GPUs!" % (epoch, trainer.hyper.lr, world))
             train_epoch(trainer, train_src, sampler, hyper, args.batch_size, epoch, reads_seed=args.reads_seed,
                         max_batches=args.max_train_batches, keep_candidate_af=args.aux_keep_candidate_af, rank=rank, world=world,
-                        all_reduce=all_reduce, gather=gather, exchange=exchange, log_interval=args.log_interval,
+                        all_reduce=all_reduce, gather=gather, exchange=exchange, prefetcher=train_loader,
+                        log_interval=args.log_interval,
                         log=lambda m: print(m, end="\r"))
             print("\n\tTime elapsed for training {:.4f}\n".format(time.time() - s), flush=True)
             s_eval = time.time()
@@ -146,7 +151,8 @@ def train_main(args, argv) -> int:
                         open(out_path, "w").close()
                     out = open(out_path, "a")
                 curloss = evaluate(net, test_src, hyper, args.test_batch_size, write=out.write if out else None,
-                                   reads_seed=args.reads_seed, max_batches=args.max_test_batches, indices=test_idx)
+                                   reads_seed=args.reads_seed, max_batches=args.max_test_batches, indices=test_idx,
+                                   prefetcher=test_loader)
                 if out:
                     out.close()
                 net.close()

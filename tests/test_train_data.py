@@ -218,3 +218,33 @@ def test_main_refuses_unsupported_training_options():
         cli.main(base + ["--augment-single-reads"])
     with pytest.raises(SystemExit, match="rm_var_reads_rate"):
         cli.main(base + ["--rm_var_reads_rate", "0.1"])
+
+
+def test_batch_prefetcher_workers_yield_the_same_batches_in_order(tmp_path):
+    """The loader workers (``--num-data-workers``; main.py:59-60) are spawned processes with their own HDF5 handles; what they
+    yield is what the in-process path assembles, in the order asked, for shuffled and ragged index lists."""
+    from dl4vc_amd import hdf5io
+    from dl4vc_amd.train_data import BatchPrefetcher, read_indices
+    from oracle.gen_golden_train import make_records
+    recs = make_records(24, 20, 900)
+    path = str(tmp_path / "train.hdf")
+    hdf5io.write_candidates(path, recs)
+    order = np.random.RandomState(3).permutation(24)
+    lists = [order[0:7], order[7:14], order[14:21], order[21:24]]
+    kw = dict(max_reads=12, seed=5, non_snp_train_weight=0.5)
+    with BatchPrefetcher(path, workers=0) as p0:
+        want = list(p0.batches(iter(lists), **kw))
+    with BatchPrefetcher(path, workers=2, depth=2) as p2:
+        got = list(p2.batches(iter(lists), **kw))
+        again = list(p2.batches(iter(lists[:2]), **kw))             # the pool serves a second epoch
+    assert len(got) == len(want) == 4 and len(again) == 2
+    for g, w, idx in zip(got, want, lists):
+        assert np.array_equal(g.index, idx) and np.array_equal(w.index, idx)
+        for a, b in zip(g.planes(), w.planes()):
+            assert np.array_equal(a, b)
+        for k in w.targets:
+            assert np.array_equal(g.targets[k], w.targets[k]), k
+        assert g.sites.vcfrec == w.sites.vcfrec and np.array_equal(g.blacklist, w.blacklist)
+    with hdf5io.CandidateFile(path) as src:
+        r = read_indices(src, np.array([5, 3, 4, 20]))
+        assert [bytes(x["name"]) for x in r] == [bytes(recs[i]["name"]) for i in (5, 3, 4, 20)]

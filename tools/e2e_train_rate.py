@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the TRAINING CLI on the GPU box: train.hdf -> main.py --train_file (loader workers, HIP training step)
+against the device-resident step rate of `bench.py --mode train`.  Usage: python tools/e2e_train_rate.py [n_sites] [workers...]"""
+import os, re, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+if __name__ == "__main__":
+    from dl4vc_amd import hdf5io
+    from oracle.gen_golden_train import make_records      # (synthetic labelled records with GT columns; test infrastructure)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    workers = [int(w) for w in sys.argv[2:]] or [0, 5]
+    td = tempfile.mkdtemp(prefix="e2e_train_")
+    base = make_records(256, 100, 900)
+    recs = np.concatenate([base] * (n // 256))
+    train = os.path.join(td, "train.hdf")
+    test = os.path.join(td, "test.hdf")
+    t0 = time.perf_counter()
+    hdf5io.write_candidates(train, recs)
+    hdf5io.write_candidates(test, base[:64])
+    print("wrote %d training records (%.1f MB on disk) in %.1f s" % (len(recs), os.path.getsize(train) / 1e6, time.perf_counter() - t0))
+    flags = ["--model-conv-layers", "7", "--model-residual-layer-start", "5", "--model-batchnorm", "--model-use-q-scores",
+             "--model-use-strands", "--model-use-reads-ref-var-mask", "--model-highway-single-reads", "--model_concat_hw_reads",
+             "--model_pool_combine_dimension", "0", "--model_middle_layer_dilation", "2", "--model_final_layer_dilation", "2",
+             "--model-hidden-dropout", "0.1", "--lr", "0.0002", "--grad-clip", "1.0", "--epochs", "1", "--log-interval", "8",
+             "--label-smoothing", "0.001", "--batch-size", "64", "--test-batch-size", "64", "--trust-snp-only", "--non-snp-train-weight", "2.0",
+             "--fp-train-weight", "0.2", "--auxillary-loss-weight", "1.0", "--auxillary-loss-bases-weight", "0.01",
+             "--auxillary-loss-allele-weight", "0.001", "--aux-keep-candidate-af", "--close_match_window", "2.0", "--focal_loss_alpha", "1.",
+             "--focal_loss_gamma", "0.2", "--close_examples_sample_rate", "0.15", "--model-ave-pool-layers", "2",
+             "--model-init-conv-channels", "128", "--model-final-conv-channels", "128", "--model-bottleneck-size", "32"]
+    for w in workers:
+        cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--train_file", train, "--test_file", test, "--modelsave",
+               os.path.join(td, "m%d.pth.tar" % w), "--num-data-workers", str(w)] + flags
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode:
+            print(r.stderr[-2000:])
+            sys.exit(1)
+        m = re.search(r"Time elapsed for training ([0-9.]+)", r.stdout)
+        tt = float(m.group(1))
+        print("--num-data-workers %d: training epoch of %d sites in %.2f s = %.0f sites/s (whole process %.1f s)" % (w, len(recs), tt, len(recs) / tt, dt))
