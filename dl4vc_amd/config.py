@@ -140,6 +140,10 @@ class DanConfig:
         for p in self.pool_layers:
             if not (1 <= p < self.layers):
                 raise UnsupportedModelOption("pool layer %d must lie in 1..layers-1" % p)
+        if self.layers == 1 and self.c_init != self.c_final:
+            # model.py:214 vs :257,275: the only layer has init_conv_channels outputs, everything after it is sized by
+            # final_conv_channels -- the reference builds such a model and fails in its first forward
+            raise UnsupportedModelOption("a single conv layer needs init_conv_channels == final_conv_channels")
         if self.bottleneck < 0 or len(self.fc_sizes) != 2:
             raise UnsupportedModelOption("bottleneck >= 0 and exactly two FC layers required")
         if self.conv_algo not in (0, 1, 2):

@@ -244,6 +244,8 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the LDS-resident path at precision %d (8..%d)", c.length, c.precision, max_len);
     if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "channel counts must be in 1..%d", CPAD);
+    if (c.layers == 1 && c.c_init != c.c_final)
+        return fail(nullptr, DAN_ERR_INVALID_ARG, "a single conv layer needs init_conv_channels == final_conv_channels (model.py:214,257)");
     if (c.bottleneck < 0 || c.bottleneck > HPAD) return fail(nullptr, DAN_ERR_INVALID_ARG, "bottleneck must be in 0..%d", HPAD);
     if (c.dil_mid < 1 || c.dil_mid > HALO || c.dil_final < 1 || c.dil_final > HALO)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "dilations must be in 1..%d", HALO);

@@ -182,6 +182,8 @@ int dan_train_create(const dan_config* cfg, const dan_train_hyper* hyper, int32_
     if (c.layers < 1 || c.layers > DAN_MAX_LAYERS) return failt(nullptr, DAN_ERR_INVALID_ARG, "layers must be in 1..%d", DAN_MAX_LAYERS);
     if (c.reads < 1 || c.length < 8 || c.length > MPOS) return failt(nullptr, DAN_ERR_INVALID_ARG, "reads >= 1 and length in 8..%d required", MPOS);
     if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD) return failt(nullptr, DAN_ERR_INVALID_ARG, "channel counts must be in 1..%d", CPAD);
+    if (c.layers == 1 && c.c_init != c.c_final)
+        return failt(nullptr, DAN_ERR_INVALID_ARG, "a single conv layer needs init_conv_channels == final_conv_channels (model.py:214,257)");
     if (c.bottleneck < 0 || c.bottleneck > HPAD) return failt(nullptr, DAN_ERR_INVALID_ARG, "bottleneck must be in 0..%d", HPAD);
     if (c.dil_mid < 1 || c.dil_mid > HALO || c.dil_final < 1 || c.dil_final > HALO) return failt(nullptr, DAN_ERR_INVALID_ARG, "dilations must be in 1..%d", HALO);
     if (c.residual_start == 1 || c.residual_start < 0) return failt(nullptr, DAN_ERR_INVALID_ARG, "Do not allow residuals starting at conv layer %d", c.residual_start);

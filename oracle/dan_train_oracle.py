@@ -97,8 +97,11 @@ def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor
         residual = x                                                 # model.py:732
         if (l - 1) in spec.pool_layers:
             x = x + pool                                             # model.py:742
-        x = F.relu(F.conv2d(x, sd["conv1D_layers.%d.weight" % (l - 1)], sd["conv1D_layers.%d.bias" % (l - 1)],
-                            padding=(0, dil), dilation=(1, dil)))    # model.py:749
+        x = F.conv2d(x, sd["conv1D_layers.%d.weight" % (l - 1)], sd["conv1D_layers.%d.bias" % (l - 1)],
+                     padding=(0, dil), dilation=(1, dil))
+        if taps is not None:
+            taps["pre%d" % l] = x.detach().numpy().copy()           # (the ReLU's input: which mask decisions sit on a rounding error)
+        x = F.relu(x)                                                # model.py:749
         if spec.use_bn:                                              # training-mode BN after the ReLU, model.py:750-751
             p = "bn1D_layers.%d." % (l - 1)
             mu = x.mean(dim=(0, 2, 3))
@@ -114,8 +117,10 @@ def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor
         if l in spec.pool_layers:
             pool = x.mean(dim=2, keepdim=True)                       # model.py:772
         if spec.bottleneck > 0:
-            h = F.relu(F.conv2d(x, sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)],
-                                sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)]))
+            h = F.conv2d(x, sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)], sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)])
+            if taps is not None:
+                taps["hpre%d" % l] = h.detach().numpy().copy()
+            h = F.relu(h)
             hw = F.conv2d(h, sd["conv1D_compression_layers.%d.weight" % (l - 1)],
                           sd["conv1D_compression_layers.%d.bias" % (l - 1)])
             hws.append(hw.squeeze(3).reshape(B, -1))

@@ -258,3 +258,12 @@ def test_cli_refuses_without_gpu(hdf_1k, tmp_path):
            "--model_pool_combine_dimension", "0", "--model_middle_layer_dilation", "2", "--model_final_layer_dilation", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode != 0 and ("no CPU path" in r.stderr or "no HIP device" in r.stderr)
+
+
+def test_single_layer_needs_equal_widths():
+    """model.py:214 vs :257,275: with one conv layer the reference sizes the layer by init_conv_channels and everything behind
+    it by final_conv_channels, and fails in its first forward when they differ; here the configuration is refused up front."""
+    from dl4vc_amd.config import DanConfig, UnsupportedModelOption
+    DanConfig(layers=1, pool_layers=(), residual_start=0, c_init=16, c_final=16)
+    with pytest.raises(UnsupportedModelOption, match="single conv layer"):
+        DanConfig(layers=1, pool_layers=(), residual_start=0, c_init=16, c_final=48)

@@ -236,3 +236,64 @@ def test_split_step_and_gradient_buckets():
     tr.backward_end()
     tr.apply()
     tr.close()
+
+
+def random_train_case(seed):
+    """A seeded random network structure + batch + targets + dropout masks for the training step."""
+    rng = np.random.default_rng(7000 + seed)
+    layers = int(rng.integers(1, 8))
+    pools = tuple(sorted(set(int(p) for p in rng.integers(1, max(layers, 2), size=int(rng.integers(0, 3))) if 1 <= p < layers)))
+    res = int(rng.choice([0] + list(range(2, layers + 1)))) if layers >= 2 else 0
+    c_init = int(rng.choice([8, 16, 48, 128]))
+    c_final = int(rng.choice([8, 16, 48, 128]))
+    if (res and res <= layers) or layers == 1:                  # a residual last layer adds x_{l-1}: same width (model.py:760)
+        c_final = c_init
+    kw = dict(reads=int(rng.integers(1, 14)), length=int(rng.integers(112, 209)), layers=layers, pool_layers=pools,
+              residual_start=res, c_init=c_init, c_final=c_final, bottleneck=int(rng.choice([0, 4, 8, 32])),
+              fc_sizes=(int(rng.choice([8, 24, 40])), int(rng.choice([4, 12]))), use_bn=bool(rng.integers(0, 4) > 0),
+              use_q=bool(rng.integers(0, 2)), use_strand=bool(rng.integers(0, 2)), use_mask=bool(rng.integers(0, 2)),
+              dil_mid=int(rng.choice([1, 2, 2, 3])), dil_final=int(rng.choice([1, 2, 2, 4])))
+    cfg = DanConfig(**kw)
+    sd = random_state_dict(cfg, seed=8000 + seed)
+    for k in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
+        sd[k + ".weight"] = (sd[k + ".weight"] * np.float32(0.1)).astype(np.float32)
+    B = int(rng.integers(1, 6))
+    batch = synth.make_sites(B, reads=cfg.reads, length=cfg.length, seed=9000 + seed)
+    hp = TrainHyper(dropout=float(rng.choice([0.0, 0.1, 0.3])), grad_clip=float(rng.choice([0.0, 1.0])),
+                    fp_train_weight=float(rng.choice([0.2, 1.0])), focal_gamma=float(rng.choice([0.0, 0.2, 2.0])),
+                    label_smoothing=float(rng.choice([0.0, 0.001, 0.05])))
+    tg = {"label": rng.integers(0, 3, B), "var_type": rng.integers(0, 3, B), "allele_freq": rng.random(B).astype(np.float32),
+          "coverage": rng.integers(1, 90, B).astype(np.float32), "var_base_enum": rng.integers(0, 10, B),
+          "var_ref_enum": rng.integers(0, 10, B), "is_snp": rng.integers(0, 2, B).astype(np.uint8)}
+    tg["weight"] = example_weights(tg["is_snp"], hp)
+    widths = (cfg.feature_width, cfg.fc_sizes[0], cfg.fc_sizes[1])
+    masks = [(rng.random((B, w)) >= hp.dropout).astype(np.uint8) for w in widths] if hp.dropout > 0 else None
+    return kw, cfg, sd, batch, hp, tg, masks
+
+
+def run_random_train_case(seed):
+    import torch
+    kw, cfg, sd, batch, hp, tg, masks = random_train_case(seed)
+    ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
+    want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64)
+    w32 = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks)
+    tr = DanTrainer(cfg, hp, max_batch=8).load_state_dict(sd)
+    out = tr.train_step(batch.arrays(), tg, dropout_masks=masks)
+    tag = "seed %d %s dropout %s" % (seed, kw, hp.dropout)
+    for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr"):
+        assert abs(out[k] - float(want[k])) <= 5e-5 * max(1.0, abs(float(want[k]))), (tag, k, out[k], float(want[k]))
+    assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * max(float(want["grad_norm"]), 1e-6), tag
+    grads = {k[5:]: v for k, v in want.items() if k.startswith("grad:")}
+    slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
+    worst = check_grads(tr, grads, tag, slack)
+    tr.close()
+    return worst
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_structures_train_step_against_float64_oracle(seed):
+    """Seeded random structures (1-7 layers, widths 8-128, pools, residual start, bottleneck 0-32, BatchNorm on/off, input
+    planes on/off, dilations 1-4, dropout, loss hyper-parameters): losses, clip norm and every gradient tensor of the HIP step
+    against the training oracle in float64 (1e-4 of the tensor's max plus twice the fp32 oracle's own distance from it).
+    tools/fuzz_train.py runs the same check over a wider seed range."""
+    run_random_train_case(seed)
