@@ -88,16 +88,19 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT16], const __bf16* xs, g
     const int total = ntaps * kg;
     const int t0 = (ntaps == 3) ? -dil : 0;
     const __bf16* xrow = xs + (HALO + pos) * S16 + kq * 8;
-    bf8 a_nxt[NT16][2], bh[MT], bl[SPLIT ? MT : 1];
+    // B fragments live in a ring of RING registers, not one per position tile: tile m sits in slot m % RING and is
+    // replaced, right after its MFMAs, by tile m + RING of the same k-step or -- for the last RING tiles -- by tile
+    // m % RING of the NEXT k-step (any RING consecutive m cover every slot, so all indices stay compile-time).  At 19
+    // position tiles that is 32 instead of 76 registers (the fragments were what spilled), with 8 MFMAs of load lead.
+    constexpr int RING = MT < 8 ? MT : 8;
+    bf8 a_nxt[NT16][2], bh[RING], bl[SPLIT ? RING : 1];
 #pragma unroll
     for (int n = 0; n < NT16; ++n) { a_nxt[n][0] = a_first[n][0]; a_nxt[n][1] = a_first[n][1]; }
-    {
-        const __bf16* xb = xrow + t0 * S16;
+    const __bf16* xc = xrow + t0 * S16;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            bh[m] = *(const bf8*)(xb + m * 16 * S16);
-            if (SPLIT) bl[m] = *(const bf8*)(xb + m * 16 * S16 + G::PLANE);
-        }
+    for (int m = 0; m < RING; ++m) {
+        bh[m] = *(const bf8*)(xc + m * 16 * S16);
+        if (SPLIT) bl[m] = *(const bf8*)(xc + m * 16 * S16 + G::PLANE);
     }
     int t = 0, g = 0;
     for (int it = 0; it < total; ++it) {
@@ -116,16 +119,18 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT16], const __bf16* xs, g
         const __bf16* xn = xrow + (t0 + tn * dil) * S16 + gn * 32;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            const int slot = m % RING;
 #pragma unroll
-            for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][0], bh[m], acc[m][n]);
+            for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][0], bh[slot], acc[m][n]);
             if (SPLIT) {
 #pragma unroll
-                for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][1], bh[m], acc[m][n]);
+                for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][1], bh[slot], acc[m][n]);
 #pragma unroll
-                for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][0], bl[m], acc[m][n]);
+                for (int n = 0; n < NT16; ++n) acc[m][n] = mfma_bf16(a[n][0], bl[slot], acc[m][n]);
             }
-            bh[m] = *(const bf8*)(xn + m * 16 * S16);
-            if (SPLIT) bl[m] = *(const bf8*)(xn + m * 16 * S16 + G::PLANE);
+            const __bf16* src = (m + RING < MT) ? xc + (m + RING) * 16 * S16 : xn + slot * 16 * S16;
+            bh[slot] = *(const bf8*)src;
+            if (SPLIT) bl[slot] = *(const bf8*)(src + G::PLANE);
         }
         __builtin_amdgcn_sched_group_barrier(0x020, NT16 * G::NP, 0);
 #pragma unroll
@@ -134,6 +139,7 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT16], const __bf16* xs, g
             __builtin_amdgcn_sched_group_barrier(0x100, G::NP, 0);
         }
         t = tn; g = gn;
+        xc = xn;
     }
 }
 
@@ -177,7 +183,9 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int 
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int pt = p0 + PS * i, p = pt * 16 + pos;
+        int po = pos;
+        asm volatile("" : "+v"(po));                             // (keeps the NB store addresses from living through the layer loop)
+        const int pt = p0 + PS * i, p = pt * 16 + po;
         if (pt < MT && p < L) {
             v4f v = acc[i];
 #pragma unroll
@@ -189,6 +197,7 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int 
 
 template <bool SPLIT, int MT>
 __device__ __forceinline__ void copy_out16(const __bf16* xs, float* dst, int L, int tid) {
+    asm volatile("" : "+v"(tid));                               // (the first store address is formed here, not ahead of the layer loop)
     for (int i = tid; i < L * (CPAD / 4); i += SEG_THREADS) {
         const int p = i >> 5, c4 = i & 31;
         ((v4f*)dst)[i] = load_cell<SPLIT, Geo<SPLIT, MT>::PLANE>(xs + (HALO + p) * S16 + c4 * 4);
@@ -373,7 +382,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
                 for (int n = 0; n < NT16; ++n) {
                     __bf16* cell = xs + (HALO + p) * S16 + chb[n];
                     v4f old = load_cell<SPLIT, G::PLANE>(cell);
-                    if (from_global) old = (p < L) ? *(const v4f*)(yrow + (size_t)p * CPAD + chb[n]) : splat4(0.f);
+                    if (from_global) {
+                        // (an opaque copy of the position: otherwise all MT row addresses are formed ahead of the layer
+                        // loop and live -- spilled -- through every GEMM for a branch one layer per segment takes)
+                        int po = pos;
+                        asm volatile("" : "+v"(po));
+                        const int pg = m * 16 + po;
+                        old = (pg < L) ? *(const v4f*)(yrow + (size_t)pg * CPAD + chb[n]) : splat4(0.f);
+                    }
                     store_cell<SPLIT, G::PLANE>(cell, acc[m][n]);
                     acc[m][n] = old + bres[n];
                 }
