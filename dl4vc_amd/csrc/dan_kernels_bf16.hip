@@ -145,9 +145,21 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[MT][NT16], const __bf16* xs, g
 
 // 128 -> 32 highway bottleneck.  Unit u = 2*pt + n is owned by wave u % NWAVE: every wave has a fixed channel
 // tile n = wave & 1 and the position tiles pt = (wave >> 1) mod (NWAVE/2).
+// (its weight fragments are requested by the caller right after the conv GEMM, a barrier and the write-back ahead of their use:
+// loaded here they cost the stage one L2 latency)
+template <bool SPLIT>
+__device__ __forceinline__ void bottleneck16_weights(bf8 (&ah)[CPAD / 32], bf8 (&al)[SPLIT ? CPAD / 32 : 1], gbf8_ptr wb, int lo_off, int wave) {
+    const int n = wave & 1;
+#pragma unroll
+    for (int g = 0; g < CPAD / 32; ++g) {
+        ah[g] = wb[(g * 2 + n) * 64];
+        if (SPLIT) al[g] = wb[(g * 2 + n) * 64 + lo_off];
+    }
+}
+
 template <bool SPLIT, int MT>
-__device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int lo_off, const float* bbot, float* hrow,
-                                             int L, int wave, int lane) {
+__device__ __forceinline__ void bottleneck16(const __bf16* xs, const bf8 (&ah)[CPAD / 32], const bf8 (&al)[SPLIT ? CPAD / 32 : 1],
+                                             const float* bbot, float* hrow, int L, int wave, int lane) {
     typedef Geo<SPLIT, MT> G;
     constexpr int PS = NWAVE / 2;
     constexpr int NB = (MT + PS - 1) / PS;
@@ -155,29 +167,32 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, gbf8_ptr wb, int 
     const int pos = lane & 15, kq = lane >> 4;
     const int n = wave & 1, p0 = wave >> 1;
     const __bf16* xrow = xs + (HALO + pos) * S16 + kq * 8;
-    bf8 ah[KG], al[SPLIT ? KG : 1];
-#pragma unroll
-    for (int g = 0; g < KG; ++g) {
-        ah[g] = wb[(g * 2 + n) * 64];
-        if (SPLIT) al[g] = wb[(g * 2 + n) * 64 + lo_off];
-    }
     v4f acc[NB];
     {
         const v4f b = *(const v4f*)(bbot + n * 16 + kq * 4);
 #pragma unroll
         for (int i = 0; i < NB; ++i) acc[i] = b;
     }
+    // every B fragment of the stage requested before the first MFMA (KG * NB of them: the conv accumulators are dead here,
+    // the registers are free): as load -> MFMA pairs the stage was one LDS latency per MFMA (3.5 k cycles for 0.3 k of MFMA)
+    bf8 bh[KG][NB], bl[SPLIT ? KG : 1][SPLIT ? NB : 1];
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int pt = min(p0 + PS * i, MT - 1);
+            bh[g][i] = *(const bf8*)(xrow + pt * 16 * S16 + g * 32);
+            if (SPLIT) bl[g][i] = *(const bf8*)(xrow + pt * 16 * S16 + g * 32 + G::PLANE);
+        }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int pt = min(p0 + PS * i, MT - 1);
-            const bf8 bh = *(const bf8*)(xrow + pt * 16 * S16 + g * 32);
-            acc[i] = mfma_bf16(ah[g], bh, acc[i]);
+            acc[i] = mfma_bf16(ah[g], bh[g][i], acc[i]);
             if (SPLIT) {
-                const bf8 bl = *(const bf8*)(xrow + pt * 16 * S16 + g * 32 + G::PLANE);
-                acc[i] = mfma_bf16(al[g], bh, acc[i]);
-                acc[i] = mfma_bf16(ah[g], bl, acc[i]);
+                acc[i] = mfma_bf16(al[g], bh[g][i], acc[i]);
+                acc[i] = mfma_bf16(ah[g], bl[g][i], acc[i]);
             }
         }
     }
@@ -347,6 +362,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         STAMP16(sb + 0);
         gemm16<SPLIT, MT, KGC>(acc, xs, w_conv, W16_CONV_FRAGS, pre_conv, kg, 3, dil, lane);
         STAMP16(sb + 1);
+        bf8 bot_h[CPAD / 32], bot_l[SPLIT ? CPAD / 32 : 1];
+        if (a.has_hw) bottleneck16_weights<SPLIT>(bot_h, bot_l, w_bot, W16_BOT_FRAGS, wave);
         {
             v4f sc[NT16], sh[NT16];
 #pragma unroll
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         STAMP16(sb + 6);
         if (a.tap && a.tap_layer == l + 1) copy_out16<SPLIT, MT>(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
         if (a.has_hw)
-            bottleneck16<SPLIT, MT>(xs, w_bot, W16_BOT_FRAGS, lc + CST_BBOT,
+            bottleneck16<SPLIT, MT>(xs, bot_h, bot_l, lc + CST_BBOT,
                                     a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
         STAMP16(sb + 7);
 #pragma unroll
