@@ -157,11 +157,14 @@ __device__ __forceinline__ void bottleneck16_weights(bf8 (&ah)[CPAD / 32], bf8 (
     }
 }
 
-template <bool SPLIT, int MT>
+// NWV = 8: a stage of its own, all waves.  NWV = 4: the DEFERRED form -- the four older waves of the workgroup (the arbiter serves
+// them first, so they reach the barrier behind the conv GEMM ~3 k cycles before the younger four) run the PREVIOUS layer's
+// bottleneck inside this layer's stage, from the same LDS image the conv GEMM just read, in that wait.
+template <bool SPLIT, int MT, int NWV>
 __device__ __forceinline__ void bottleneck16(const __bf16* xs, const bf8 (&ah)[CPAD / 32], const bf8 (&al)[SPLIT ? CPAD / 32 : 1],
                                              const float* bbot, float* hrow, int L, int wave, int lane) {
     typedef Geo<SPLIT, MT> G;
-    constexpr int PS = NWAVE / 2;
+    constexpr int PS = NWV / 2;
     constexpr int NB = (MT + PS - 1) / PS;
     constexpr int KG = CPAD / 32;
     const int pos = lane & 15, kq = lane >> 4;
@@ -173,28 +176,34 @@ __device__ __forceinline__ void bottleneck16(const __bf16* xs, const bf8 (&ah)[C
 #pragma unroll
         for (int i = 0; i < NB; ++i) acc[i] = b;
     }
-    // every B fragment of the stage requested before the first MFMA (KG * NB of them: the conv accumulators are dead here,
-    // the registers are free): as load -> MFMA pairs the stage was one LDS latency per MFMA (3.5 k cycles for 0.3 k of MFMA)
-    bf8 bh[KG][NB], bl[SPLIT ? KG : 1][SPLIT ? NB : 1];
+    // B fragments are requested in batches ahead of their MFMAs (as load -> MFMA pairs the stage was one LDS latency per MFMA:
+    // 3.5 k cycles for 0.3 k of MFMA).  As a stage of its own the conv accumulators are dead and the whole stage is one batch;
+    // the deferred form runs beside live conv accumulators: one k-group per batch.
+    constexpr int GB = (NWV == NWAVE) ? KG : 1;                  // k-groups per batch
 #pragma unroll
-    for (int g = 0; g < KG; ++g)
+    for (int g0 = 0; g0 < KG; g0 += GB) {
+        bf8 bh[GB][NB], bl[SPLIT ? GB : 1][SPLIT ? NB : 1];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int pt = min(p0 + PS * i, MT - 1);
-            bh[g][i] = *(const bf8*)(xrow + pt * 16 * S16 + g * 32);
-            if (SPLIT) bl[g][i] = *(const bf8*)(xrow + pt * 16 * S16 + g * 32 + G::PLANE);
-        }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < GB; ++g)
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
+            for (int i = 0; i < NB; ++i) {
+                const int pt = min(p0 + PS * i, MT - 1);
+                bh[g][i] = *(const bf8*)(xrow + pt * 16 * S16 + (g0 + g) * 32);
+                if (SPLIT) bl[g][i] = *(const bf8*)(xrow + pt * 16 * S16 + (g0 + g) * 32 + G::PLANE);
+            }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            acc[i] = mfma_bf16(ah[g], bh[g][i], acc[i]);
-            if (SPLIT) {
-                acc[i] = mfma_bf16(al[g], bh[g][i], acc[i]);
-                acc[i] = mfma_bf16(ah[g], bl[g][i], acc[i]);
+        for (int g = 0; g < GB; ++g) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                acc[i] = mfma_bf16(ah[g0 + g], bh[g][i], acc[i]);
+                if (SPLIT) {
+                    acc[i] = mfma_bf16(al[g0 + g], bh[g][i], acc[i]);
+                    acc[i] = mfma_bf16(ah[g0 + g], bl[g][i], acc[i]);
+                }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -362,8 +371,21 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         STAMP16(sb + 0);
         gemm16<SPLIT, MT, KGC>(acc, xs, w_conv, W16_CONV_FRAGS, pre_conv, kg, 3, dil, lane);
         STAMP16(sb + 1);
+        // bottleneck schedule: the bf16 kernels defer layer l's 128 -> 32 GEMM into layer l + 1's stage (older four waves, in
+        // their wait at the barrier below); the segment's last layer keeps a stage of its own.  (The bf16x3 kernels have no
+        // registers for it.)
+        constexpr bool DEFER = !SPLIT;
         bf8 bot_h[CPAD / 32], bot_l[SPLIT ? CPAD / 32 : 1];
-        if (a.has_hw) bottleneck16_weights<SPLIT>(bot_h, bot_l, w_bot, W16_BOT_FRAGS, wave);
+        if (DEFER) {
+            if (a.has_hw && l > a.l_begin && wave < NWAVE / 2) {
+                bottleneck16_weights<SPLIT>(bot_h, bot_l, (gbf8_ptr)(block(l - 1) + W16_BOT_OFF) + lane, W16_BOT_FRAGS, wave);
+                bottleneck16<SPLIT, MT, NWAVE / 2>(xs, bot_h, bot_l, lc - CST_FLOATS + CST_BBOT,
+                                                   a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            }
+            if (a.has_hw && l + 1 == a.l_end) bottleneck16_weights<SPLIT>(bot_h, bot_l, w_bot, W16_BOT_FRAGS, wave);
+        } else if (a.has_hw) {
+            bottleneck16_weights<SPLIT>(bot_h, bot_l, w_bot, W16_BOT_FRAGS, wave);
+        }
         {
             v4f sc[NT16], sh[NT16];
 #pragma unroll
@@ -435,9 +457,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment16_kernel(Segme
         __syncthreads();
         STAMP16(sb + 6);
         if (a.tap && a.tap_layer == l + 1) copy_out16<SPLIT, MT>(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
-        if (a.has_hw)
-            bottleneck16<SPLIT, MT>(xs, bot_h, bot_l, lc + CST_BBOT,
-                                    a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+        if (a.has_hw && (!DEFER || l + 1 == a.l_end))
+            bottleneck16<SPLIT, MT, NWAVE>(xs, bot_h, bot_l, lc + CST_BBOT,
+                                           a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
         STAMP16(sb + 7);
 #pragma unroll
         for (int n = 0; n < NT16; ++n) { pre_conv[n][0] = pre_next[n][0]; pre_conv[n][1] = pre_next[n][1]; }
