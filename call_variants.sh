@@ -1,23 +1,36 @@
 #!/bin/bash
-# Drop-in for the INFERENCE STAGES of the reference's call_variants.sh (call_variants.sh:99-168): scoring of
-# an existing candidates.hdf with the MI355X-native DAN forward, then sort, genotype thresholds, multi-allele join and
-# bgzip/tabix (with bcftools/htslib when installed, else in process: dl4vc_amd/vcfpost.py).  The BAM -> candidates.vcf -> candidates.hdf stages
-# (pysam pileup, reference call_variants.sh:76-97) are CPU pre-processing outside this implementation: run
-# them with the reference's tools, or pass an existing OUTDIR that already holds candidates.{vcf,hdf}.
+# Drop-in for the reference's call_variants.sh from the candidate VCF on (call_variants.sh:85-168): candidates.vcf + BAM ->
+# candidates.hdf (tools/convert_bam_single_reads.py here: own BAM / FASTA readers, no pysam), scoring with the MI355X-native DAN
+# forward, then sort, genotype thresholds, multi-allele join and bgzip/tabix (with bcftools/htslib when installed, else in
+# process: dl4vc_amd/vcfpost.py).  The first stage -- BAM -> candidates.vcf (tools/candidate_generator.py, reference
+# call_variants.sh:76-83) -- is CPU pre-processing outside this implementation: OUTDIR must already hold candidates.vcf.
+# With an OUTDIR that also holds candidates.hdf, -i / -r are not needed and the conversion is skipped.
 set -e
-usage() { echo "Usage: $0 -m MODEL -o OUTDIR [-g GPUS]   (OUTDIR must hold candidates.hdf and candidates.vcf)"; exit 1; }
+usage() { echo "Usage: $0 -m MODEL -o OUTDIR [-i BAM -r REFERENCE] [-g GPUS] [-p PROCESSES]   (OUTDIR must hold candidates.vcf)"; exit 1; }
 GPUS=1
-while getopts "m:o:g:h" opt; do
+PROCS=16
+while getopts "m:o:g:i:r:b:p:h" opt; do
   case $opt in
     m) MODEL=$OPTARG ;;
     o) OUTDIR=$OPTARG ;;
     g) GPUS=$OPTARG ;;
+    i) BAM=$OPTARG ;;
+    r) REFERENCE=$OPTARG ;;
+    b) BED=$OPTARG ;;       # (accepted for compatibility with the reference's flag line; only candidate generation uses it)
+    p) PROCS=$OPTARG ;;
     *) usage ;;
   esac
 done
 [ -z "$MODEL" ] || [ -z "$OUTDIR" ] && usage
 SCRIPTDIR="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-[ -f "$OUTDIR/candidates.hdf" ] || { echo "missing $OUTDIR/candidates.hdf"; exit 1; }
+if [ ! -f "$OUTDIR/candidates.hdf" ]; then
+  [ -f "$OUTDIR/candidates.vcf" ] && [ -n "$BAM" ] && [ -n "$REFERENCE" ] || { echo "missing $OUTDIR/candidates.hdf (or candidates.vcf with -i BAM -r REFERENCE to make it)"; exit 1; }
+  printf "Convert candidates to HDF...\n"
+  python "$SCRIPTDIR/tools/convert_bam_single_reads.py" --input "$BAM" --fp_vcf "$OUTDIR/candidates.vcf" \
+      --fasta-input "$REFERENCE" --output "$OUTDIR/candidates.hdf" --max-reads 200 --num-processes "$PROCS" \
+      --locations-process-step 100000 --max-insert-length 10 --max-insert-length-variant 50 \
+      --save-q-scores --save-strand > "$OUTDIR/training_data.log" 2>&1
+fi
 
 printf "Run inference...\n"
 python "$SCRIPTDIR/main.py" \

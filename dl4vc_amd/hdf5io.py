@@ -19,7 +19,7 @@ from .hdf5_schema import DATASET_NAME, record_dtype
 
 hid_t = C.c_int64
 hsize_t = C.c_uint64
-H5F_ACC_RDONLY, H5F_ACC_TRUNC = 0x0000, 0x0002
+H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0x0000, 0x0001, 0x0002
 H5S_SELECT_SET = 0
 H5T_COMPOUND = 6
 H5S_UNLIMITED = 0xFFFFFFFFFFFFFFFF
@@ -274,3 +274,47 @@ def records_from_sites(batch, store_reads: int = 200, label: int = 2) -> np.ndar
         recs[i]["label"] = label
         recs[i]["vcfrec"] = batch.vcfrec[i].encode()[:128]
     return recs
+
+
+def append_candidates(path: str, records: np.ndarray) -> int:
+    """Extend the ``data`` dataset of an existing file by ``records`` (the converter's ``df.resize`` + slice assignment,
+    convert_bam_single_reads.py:660-671); returns the new length."""
+    h5 = _h5py()
+    if h5 is not None:
+        with h5.File(path, "a") as f:
+            d = f[DATASET_NAME]
+            n0 = d.shape[0]
+            d.resize((n0 + len(records),))
+            d[n0:] = records
+            return n0 + len(records)
+    lib = libhdf5()
+    fid = lib.H5Fopen(path.encode(), H5F_ACC_RDWR, 0)
+    if fid < 0:
+        raise OSError("cannot open %s for appending" % path)
+    did = lib.H5Dopen2(fid, DATASET_NAME.encode(), 0)
+    if did < 0:
+        lib.H5Fclose(fid)
+        raise KeyError("%s has no dataset '%s'" % (path, DATASET_NAME))
+    sid = lib.H5Dget_space(did)
+    dims = (hsize_t * 1)()
+    lib.H5Sget_simple_extent_dims(sid, dims, None)
+    lib.H5Sclose(sid)
+    n0, n = int(dims[0]), len(records)
+    rc = 0
+    if n:
+        rc = lib.H5Dset_extent(did, (hsize_t * 1)(n0 + n))
+        tid = _h5_compound_type(lib, records.dtype)
+        fs = lib.H5Dget_space(did)
+        count = (hsize_t * 1)(n)
+        lib.H5Sselect_hyperslab(fs, H5S_SELECT_SET, (hsize_t * 1)(n0), None, count, None)
+        ms = lib.H5Screate_simple(1, count, None)
+        buf = np.ascontiguousarray(records)
+        if rc >= 0:
+            rc = lib.H5Dwrite(did, tid, ms, fs, 0, buf.ctypes.data_as(C.c_void_p))
+        for closer, h in ((lib.H5Sclose, ms), (lib.H5Sclose, fs), (lib.H5Tclose, tid)):
+            closer(h)
+    lib.H5Dclose(did)
+    lib.H5Fclose(fid)
+    if rc < 0:
+        raise OSError("appending %d records to %s failed" % (n, path))
+    return n0 + n

@@ -171,3 +171,57 @@ def test_bench_train_two_rank_launch_path():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["unit"] == "sites/s" and rec["config"]["sites_per_gpu_per_step"] == 4
     assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 8) < 0.01 and np.isfinite(rec["last_step"]["loss"])
+
+
+def test_call_variants_sh_from_bam_and_candidate_vcf(tmp_path):
+    """call_variants.sh -i BAM -r REF with an OUTDIR that holds only candidates.vcf: the pileup encoder (own BAM / FASTA readers)
+    makes candidates.hdf, main.py scores it on the GPU, the VCF back end finishes called_variants.vcf.gz; the scores of the
+    scored VCF equal the oracle's on the sites assembled from the encoded records."""
+    import gzip
+    import torch
+    from dl4vc_amd.bamio import BamWriter, build_bai, CMATCH, CINS, FREVERSE
+    from dl4vc_amd.dataset import assemble_batch
+    rng = np.random.default_rng(33)
+    ref = "".join(rng.choice(list("ACGT"), 4000))
+    out = tmp_path / "out"
+    out.mkdir()
+    fa = str(tmp_path / "ref.fa")
+    open(fa, "w").write(">chr20\n" + "\n".join(ref[i:i + 60] for i in range(0, 4000, 60)) + "\n")
+    positions = [700, 1210, 1850, 2400, 3100]
+    alts = {p: ("A" if ref[p - 1] != "A" else "C") for p in positions}
+    bam = str(tmp_path / "reads.bam")
+    starts = np.sort(rng.integers(300, 3500, 700))
+    with BamWriter(bam, [("chr20", 4000)]) as w:
+        for i, s in enumerate(starts):
+            s, n = int(s), 150
+            seq, cigar = list(ref[s:s + n]), [(CMATCH, n)]
+            for p in positions:
+                if s <= p - 1 < s + n and i % 2 == 0:
+                    seq[p - 1 - s] = alts[p]
+            if s < 1850 - 1 < s + n - 1 and i % 4 == 0:
+                k = 1850 - s
+                seq, cigar = seq[:k] + list("TT") + seq[k:], [(CMATCH, k), (CINS, 2), (CMATCH, n - k)]
+            w.write(0, s, "frag%d" % i, FREVERSE if i % 2 else 0, 60, cigar, "".join(seq), rng.integers(15, 41, len(seq)).tolist())
+    build_bai(bam, bam + ".bai")
+    open(str(out / "candidates.vcf"), "w").write(
+        "##fileformat=VCFv4.2\n##contig=<ID=chr20,length=4000>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n" +
+        "".join("chr20\t%d\t.\t%s\t%s\t50\t.\tDP=40;AF=0.5\tGT\t0/1\n" % (p, ref[p - 1], alts[p]) for p in positions))
+    cfg = DanConfig()
+    sd = random_state_dict(cfg, seed=14)
+    ck = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"epoch": 1, "best_loss": 0.0, "optimizer": {}, "state_dict": {"module." + k: torch.from_numpy(v) for k, v in sd.items()}}, ck)
+    r = subprocess.run(["bash", os.path.join(ROOT, "call_variants.sh"), "-m", ck, "-o", str(out), "-i", bam, "-r", fa, "-p", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:], open(str(out / "training.log")).read()[-1500:] if (out / "training.log").exists() else "")
+    with hdf5io.CandidateFile(str(out / "candidates.hdf")) as f:
+        recs = f.read(0, len(f))
+    assert len(recs) == 5 and [bytes(x).rstrip(b"\x00").decode() for x in recs["name"]] == ["chr20:%d" % p for p in positions]
+    scored = [l for l in open(str(out / "epoch1_model_test.vcf")).read().splitlines() if not l.startswith("#")]
+    assert len(scored) == 5
+    batch = assemble_batch(recs, cfg.reads, seed=0)
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    got = np.array([_scores(l) for l in scored])
+    k = got.shape[1] - 1
+    assert np.abs(got[:, 0] - want["bp"].reshape(-1)).max() < 1e-4 and np.abs(got[:, 1:] - want["vt_prob"][:, :k]).max() < 1e-4
+    assert gzip.open(str(out / "called_variants.vcf.gz"), "rt").read().startswith("##fileformat")
+    assert os.path.isfile(str(out / "called_variants.vcf.gz.tbi"))
