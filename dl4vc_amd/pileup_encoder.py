@@ -19,7 +19,7 @@ How a location becomes a record, as the reference does it:
 * crop to ``w`` columns either side of the candidate's column, drop leading all-zero rows, keep the middle ``--max-reads``
   rows, pad into ``(max_reads, 2w + 1)``.
 
-Parity: the image logic above is PINNED -- tests/golden/pileup_encoder.npz holds outputs of the reference's own helper
+Parity: the image logic above is PINNED -- tests/golden/pileup_encoder.json.gz holds outputs of the reference's own helper
 functions (executed from its source by oracle/gen_golden_pileup.py on synthetic pileup columns) and of this module's
 ``process_columns`` glue is compared against a transcription of the reference's loop driven by those helpers.  The BAM side
 (dl4vc_amd/bamio.py, dl4vc_amd/pileup.py) is UNPINNED: no htslib / pysam in the image.
@@ -270,8 +270,10 @@ def locations_from_vcf(path: str, label: int, full_vcf: Optional[str] = None) ->
     return out
 
 
-def encode_location(bam, fasta, loc: Location, opt: EncoderOptions):
-    """``process_location`` (:846-1118) for one candidate against an open ``BamFile`` / ``FastaFile``."""
+def encode_location(bam, fasta, loc: Location, opt: EncoderOptions, reader=None):
+    """``process_location`` (:846-1118) for one candidate against an open ``BamFile`` / ``FastaFile``.  ``reader``: a
+    ``bamio.WindowReader`` on ``bam`` shared by a run of locations (each alignment is then parsed once, not once per
+    location)."""
     from .pileup import pileup_columns
     window = opt.window_size + 2
     start, stop = loc.pos - window, loc.pos + window + 1
@@ -282,7 +284,7 @@ def encode_location(bam, fasta, loc: Location, opt: EncoderOptions):
     ref = fasta.fetch(loc.contig, s0, stop + 64)
 
     def cols():
-        for c in pileup_columns(bam.fetch(tid, s0, stop), s0, stop):
+        for c in pileup_columns(reader.reads(tid, s0, stop) if reader is not None else bam.fetch(tid, s0, stop), s0, stop):
             seqs = c.query_sequences(opt.min_base_quality)
             o = c.reference_pos - s0
             yield ColumnInput(c.reference_pos, seqs, c.query_qualities(opt.min_base_quality), c.query_ids(opt.min_base_quality),
@@ -292,14 +294,15 @@ def encode_location(bam, fasta, loc: Location, opt: EncoderOptions):
 
 def encode_locations(bam_path: str, fasta_path: str, locations: Sequence[Location], opt: EncoderOptions) -> Tuple[np.ndarray, int]:
     """Records for ``locations`` in input order and the number of locations that produced none."""
-    from .bamio import BamFile, FastaFile
+    from .bamio import BamFile, FastaFile, WindowReader
     dtype = record_dtype(opt.max_reads, 2 * opt.window_size + 1)
     out = np.zeros(len(locations), dtype)
     n = errors = 0
     with BamFile(bam_path) as bam:
         fasta = FastaFile(fasta_path)
+        reader = WindowReader(bam)
         for loc in locations:
-            res = encode_location(bam, fasta, loc, opt)
+            res = encode_location(bam, fasta, loc, opt, reader)
             rec = finish_record(res, loc, opt, dtype) if res is not None else None
             if rec is None:
                 errors += 1

@@ -340,3 +340,24 @@ def test_converter_cli_chunks_appends_and_worker_processes(tmp_path):
     assert bytes(ra["vcfrec"][0]).rstrip(b"\x00").endswith(b"\tGT:1/1") and not bytes(ra["vcfrec"][20]).rstrip(b"\x00").endswith(b"GT:0/1\tGT:0/1")
     r = subprocess.run([sys.executable, tool, "--output", one, "--num-processes", "1", "--restrict_locations"] + common, capture_output=True, text=True)
     assert r.returncode != 0 and "not supported" in r.stderr
+
+
+def test_window_reader_equals_fetch_for_forward_backward_and_far_queries(tmp_path):
+    rng = np.random.default_rng(8)
+    p = str(tmp_path / "w.bam")
+    starts = np.sort(rng.integers(0, 300000, 3000))
+    with BamWriter(p, [("a", 400000), ("b", 1000)]) as w:
+        for i, s in enumerate(starts):
+            n = int(rng.integers(40, 151))
+            w.write(0, int(s), "q%d" % i, 0, 60, [(CMATCH, n)], "A" * n, [30] * n)
+        w.write(1, 10, "onb", 0, 60, [(CMATCH, 50)], "C" * 50, [30] * 50)
+    for indexed in (False, True):
+        if indexed:
+            build_bai(p, p + ".bai")
+        with BamFile(p) as bam:
+            win = bamio.WindowReader(bam)
+            queries = [(0, 1000, 1205), (0, 1100, 1305), (0, 1100, 1305), (0, 1300, 1505), (0, 50000, 50205), (0, 50100, 50305),
+                       (0, 200, 405), (0, 299000, 299900), (0, 390000, 390100), (1, 0, 100), (0, 150000, 150205), (0, 150001, 150206)]
+            for tid, lo, hi in queries:
+                got = [r.name for r in win.reads(tid, lo, hi)]
+                assert got == [r.name for r in bam.fetch(tid, lo, hi)], (indexed, tid, lo, hi)
