@@ -157,10 +157,8 @@ def _quality(e: PileupEntry) -> int:
     return int(q[e.qpos]) if e.qpos < len(q) else 0
 
 
-def pileup_columns(reads: Iterable[BamRecord], start: int, stop: int, flag_mask: int = DEFAULT_FLAG_MASK,
-                   max_depth: int = 8000) -> Iterator[PileupColumn]:
-    """Columns of ``[start, stop)`` (0-based) from ``reads``: the records of one reference overlapping the window, in file
-    (coordinate) order."""
+def resolve_reads(reads: Iterable[BamRecord], flag_mask: int = DEFAULT_FLAG_MASK) -> List[ReadTrack]:
+    """The reads that enter a pileup, resolved against the reference, in file order."""
     tracks: List[ReadTrack] = []
     for rec in reads:
         if rec.flag & flag_mask or rec.tid < 0:
@@ -168,6 +166,15 @@ def pileup_columns(reads: Iterable[BamRecord], start: int, stop: int, flag_mask:
         if not any(op in _REF_OPS for op, _ in rec.cigar):
             continue
         tracks.append(ReadTrack(rec))
+    return tracks
+
+
+def pileup_columns(reads: Iterable[BamRecord], start: int, stop: int, flag_mask: int = DEFAULT_FLAG_MASK,
+                   max_depth: int = 8000, tracks: Optional[List[ReadTrack]] = None) -> Iterator[PileupColumn]:
+    """Columns of ``[start, stop)`` (0-based) from ``reads``: the records of one reference overlapping the window, in file
+    (coordinate) order (or from ``tracks`` = ``resolve_reads(reads)``)."""
+    if tracks is None:
+        tracks = resolve_reads(reads, flag_mask)
     active: List[ReadTrack] = []
     nxt = 0
     pos = min((t.start for t in tracks), default=stop)

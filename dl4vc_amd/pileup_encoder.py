@@ -194,6 +194,115 @@ def process_columns(columns: Iterable[ColumnInput], center_position: int, opt: E
     return img[:n_rows, :col + 1], center, colmap, qimg[:n_rows, :col + 1], simg[:n_rows, :col + 1]
 
 
+# ---- the same images built read by read (numpy per row instead of Python per pileup entry) --------------------------------
+_TOKEN = np.zeros(256, np.uint8)
+_KNOWN = np.zeros(256, bool)
+for _c, _v in BASE_ENUM.items():
+    if len(_c) == 1:
+        _TOKEN[ord(_c)], _KNOWN[ord(_c)] = _v, True
+
+
+def process_tracks(tracks, s0: int, stop: int, center_position: int, opt: EncoderOptions, ref: str, ref_start: int):
+    """``process_columns`` for the common case, one read at a time: same result, ~10x faster.  Returns ``NotImplemented`` when
+    the location needs the column-by-column path -- two reads sharing a ``name:sequence`` key (they share and swap image
+    rows in the reference), a reference skip, a base outside the token table, more than 1000 columns, a depth beyond
+    pysam's cap or ``--min-base-quality`` -- so those keep the reference's exact column order of operations."""
+    if opt.min_base_quality > 0 or len(tracks) > 8000:
+        return NotImplemented
+    tracks = [t for t in tracks if t.end > s0 and t.start < stop]
+    keys = {t.key for t in tracks}
+    if len(keys) != len(tracks):
+        return NotImplemented
+    n_pos = stop - s0
+    cover = np.zeros(n_pos + 1, np.int32)
+    longest = np.zeros(n_pos, np.int32)
+    cap = np.full(n_pos, opt.max_insert_length, np.int32)
+    ci = center_position - 1 - s0
+    if 0 <= ci < n_pos:
+        cap[ci] = max(opt.max_insert_length_variant, opt.max_insert_length)
+    spans = []
+    for t in tracks:
+        lo, hi = max(t.start, s0), min(t.end, stop)
+        if t.is_refskip[lo - t.start:hi - t.start].any():
+            return NotImplemented
+        cover[lo - s0] += 1
+        cover[hi - s0] -= 1
+        ins = t.indel[lo - t.start:hi - t.start]
+        if (ins > 0).any():
+            np.maximum(longest[lo - s0:hi - s0], np.minimum(np.maximum(ins, 0), cap[lo - s0:hi - s0]), out=longest[lo - s0:hi - s0])
+        spans.append((lo, hi))
+    covered = np.cumsum(cover[:-1]) > 0
+    pos_idx = np.nonzero(covered)[0]
+    if len(pos_idx) == 0 or not (0 <= ci < n_pos and covered[ci]):
+        return None
+    if len(pos_idx) > 1001:
+        return NotImplemented
+    width = 1 + longest[pos_idx]
+    col_of = np.zeros(n_pos, np.int64)
+    col_of[pos_idx] = 1 + np.concatenate(([0], np.cumsum(width)[:-1]))
+    prev_col = np.zeros(n_pos, np.int64)
+    prev_col[pos_idx] = np.concatenate(([0], col_of[pos_idx][:-1]))
+    end_col = int(col_of[pos_idx[-1]] + width[-1])                  # the column the loop would give the next position
+    order = sorted(range(len(tracks)), key=lambda i: (spans[i][0], i))
+    n_rows = len(tracks)
+    n_cols = end_col + 1
+    img = np.zeros((n_rows, n_cols), np.uint8)
+    qimg = np.zeros_like(img)
+    simg = np.zeros_like(img)
+    for row, i in enumerate(order):
+        t = tracks[i]
+        rec = t.rec
+        lo, hi = spans[i]
+        a, b = lo - t.start, hi - t.start
+        cols = col_of[lo - s0:hi - s0]
+        qpos, dele = t.qpos[a:b], t.is_del[a:b]
+        seq = np.frombuffer(rec.seq.encode("ascii"), np.uint8)
+        inside = qpos < len(seq)
+        chars = np.where(inside, seq[np.minimum(qpos, len(seq) - 1)], ord("N"))
+        if not _KNOWN[chars].all():
+            return NotImplemented
+        strand = STRAND_LOWER if rec.is_reverse else STRAND_UPPER
+        img[row, cols] = np.where(dele, BASE_ENUM["*"], _TOKEN[chars])
+        quals = np.where(qpos < len(rec.qual), rec.qual[np.minimum(qpos, len(rec.qual) - 1)], 0).astype(np.uint8)
+        qimg[row, cols] = quals
+        simg[row, cols] = np.where(dele, STRAND_PAD, strand)
+        if t.start >= s0:                                            # head column inside the window
+            pc = prev_col[lo - s0]
+            img[row, pc], qimg[row, pc], simg[row, pc] = START, quals[0], STRAND_PAD if dele[0] else strand
+        ins = t.indel[a:b]
+        lg = longest[lo - s0:hi - s0]
+        for k in np.nonzero(lg > 0)[0]:
+            c0, m = int(cols[k]) + 1, int(lg[k])
+            st = STRAND_PAD if dele[k] else strand
+            if ins[k] > 0:
+                n_ins = min(int(ins[k]), int(cap[lo - s0 + k]))
+                if n_ins > 0:
+                    q0 = int(qpos[k])
+                    letters = [rec.seq[q0 + j] if q0 + j < len(rec.seq) else "N" for j in range(1, n_ins + 1)]
+                    toks = _TOKEN[np.frombuffer("".join(letters).encode("ascii"), np.uint8)]
+                    if not _KNOWN[np.frombuffer("".join(letters).encode("ascii"), np.uint8)].all():
+                        return NotImplemented
+                    img[row, c0:c0 + n_ins] = toks
+                    qimg[row, c0:c0 + n_ins] = quals[k]
+                    simg[row, c0:c0 + n_ins] = st
+            blk = img[row, c0:c0 + m]
+            blk[blk == PAD] = NOINSERT
+        if t.end <= stop:                                            # tail column inside the window
+            k = b - a - 1
+            e = int(cols[k]) + int(lg[k]) + 1
+            img[row, e], qimg[row, e], simg[row, e] = END, quals[k], STRAND_PAD if dele[k] else strand
+        pads = simg[row] == STRAND_PAD
+        if pads.any():
+            rest = simg[row][~pads]
+            v = int(rest.max()) if len(rest) else 0
+            simg[row][pads] = v if v else STRAND_UPPER
+    colmap = {}
+    for i, p in enumerate(pos_idx):
+        o = s0 + int(p) - ref_start
+        colmap[i] = (int(col_of[p]), s0 + int(p), ref[o:o + 1])
+    return img, int(col_of[ci]), colmap, qimg, simg
+
+
 def _trim_top(image: np.ndarray) -> np.ndarray:
     """``trim_empty_rows(image, "top")`` (:431-461): rows before the first one with a non-zero sum go (none when all are zero)."""
     sums = image.sum(axis=1)
@@ -274,7 +383,7 @@ def encode_location(bam, fasta, loc: Location, opt: EncoderOptions, reader=None)
     """``process_location`` (:846-1118) for one candidate against an open ``BamFile`` / ``FastaFile``.  ``reader``: a
     ``bamio.WindowReader`` on ``bam`` shared by a run of locations (each alignment is then parsed once, not once per
     location)."""
-    from .pileup import pileup_columns
+    from .pileup import pileup_columns, resolve_reads
     window = opt.window_size + 2
     start, stop = loc.pos - window, loc.pos + window + 1
     tid = bam.get_tid(loc.contig)
@@ -283,8 +392,13 @@ def encode_location(bam, fasta, loc: Location, opt: EncoderOptions, reader=None)
     s0 = max(start, 0)
     ref = fasta.fetch(loc.contig, s0, stop + 64)
 
+    tracks = resolve_reads(reader.reads(tid, s0, stop) if reader is not None else bam.fetch(tid, s0, stop))
+    fast = process_tracks(tracks, s0, stop, loc.pos, opt, ref, s0)
+    if fast is not NotImplemented:
+        return fast
+
     def cols():
-        for c in pileup_columns(reader.reads(tid, s0, stop) if reader is not None else bam.fetch(tid, s0, stop), s0, stop):
+        for c in pileup_columns((), s0, stop, tracks=tracks):
             seqs = c.query_sequences(opt.min_base_quality)
             o = c.reference_pos - s0
             yield ColumnInput(c.reference_pos, seqs, c.query_qualities(opt.min_base_quality), c.query_ids(opt.min_base_quality),

@@ -153,10 +153,9 @@ def crop_and_pad(R, result, window_size, max_reads):
 # ------------------------------------------------------------------------------------------------------
 # synthetic pileups
 # ------------------------------------------------------------------------------------------------------
-def simulate_case(seed, window_size, n_reads, contig_len=600, duplicate_ids=False, deep=False):
-    """Columns of simulated reads around a candidate position, made with dl4vc_amd.pileup (inputs only: the fixture stores them)."""
+def simulate_reads(seed, window_size, n_reads, contig_len=600, duplicate_ids=False):
+    """(reference sequence, candidate POS, simulated reads in coordinate order)."""
     from dl4vc_amd.bamio import BamRecord, CMATCH, CINS, CDEL, CSOFT_CLIP, FREVERSE
-    from dl4vc_amd.pileup import pileup_columns
     rng = np.random.default_rng(seed)
     ref = "".join(rng.choice(list("ACGT"), contig_len))
     if seed % 3 == 0:
@@ -209,6 +208,13 @@ def simulate_case(seed, window_size, n_reads, contig_len=600, duplicate_ids=Fals
         flag = FREVERSE if rng.random() < 0.5 else 0
         reads.append(BamRecord(0, start, int(rng.integers(0, 61)), flag, name, tuple(cigar), "".join(seq), qual))
     reads.sort(key=lambda r: r.pos)
+    return ref, center, reads
+
+
+def simulate_case(seed, window_size, n_reads, contig_len=600, duplicate_ids=False, deep=False):
+    """Columns of simulated reads around a candidate position, made with dl4vc_amd.pileup (inputs only: the fixture stores them)."""
+    from dl4vc_amd.pileup import pileup_columns
+    ref, center, reads = simulate_reads(seed, window_size, n_reads, contig_len, duplicate_ids)
     w = window_size + 2
     s0, stop = max(center - w, 0), center + w + 1
     cols = []

@@ -361,3 +361,40 @@ def test_window_reader_equals_fetch_for_forward_backward_and_far_queries(tmp_pat
             for tid, lo, hi in queries:
                 got = [r.name for r in win.reads(tid, lo, hi)]
                 assert got == [r.name for r in bam.fetch(tid, lo, hi)], (indexed, tid, lo, hi)
+
+
+def test_read_by_read_builder_equals_the_pinned_column_builder():
+    """``process_tracks`` (numpy per read) against ``process_columns`` (the column-by-column form the golden vectors pin) on
+    simulated pileups with insertions beyond both caps, deletions, soft clips and both strands; it declines (NotImplemented)
+    what only the column order of operations reproduces: duplicated read keys, reference skips, --min-base-quality."""
+    from oracle.gen_golden_pileup import simulate_reads
+    from dl4vc_amd.pileup import resolve_reads
+    n_fast = 0
+    for seed in range(40):
+        w = [100, 100, 30, 16][seed % 4]
+        opt = PE.EncoderOptions(window_size=w, max_reads=200, max_insert_length=[10, 3, 0][seed % 3], max_insert_length_variant=[50, 5, 0][seed % 3])
+        ref, center, reads = simulate_reads(100 + seed, w, [8, 40, 90, 300][seed % 4], duplicate_ids=(seed % 10 == 9))
+        s0, stop = max(center - (w + 2), 0), center + (w + 2) + 1
+        tracks = resolve_reads(reads)
+        fast = PE.process_tracks(tracks, s0, stop, center, opt, ref, 0)
+        cols = [PE.ColumnInput(c.reference_pos, c.query_sequences(), c.query_qualities(), c.query_ids(), ref[c.reference_pos:c.reference_pos + 1])
+                for c in pileup_columns((), s0, stop, tracks=tracks)]
+        slow = PE.process_columns(cols, center, opt)
+        assert fast is not NotImplemented                            # (duplicated NAMES with different sequences are distinct keys)
+        if slow is None:
+            assert fast is None
+            continue
+        n_fast += 1
+        for k, name in ((0, "image"), (3, "quality"), (4, "strand")):
+            assert fast[k].shape == slow[k].shape and np.array_equal(fast[k], slow[k]), (seed, name)
+        assert fast[1] == slow[1] and fast[2] == slow[2], seed
+    assert n_fast >= 30
+    ref, center, reads = simulate_reads(7, 30, 20)
+    twin = reads[3]
+    reads = sorted(reads + [bamio.BamRecord(0, twin.pos + 9, twin.mapq, twin.flag, twin.name, twin.cigar, twin.seq, twin.qual)], key=lambda r: r.pos)
+    assert PE.process_tracks(resolve_reads(reads), max(center - 32, 0), center + 33, center, PE.EncoderOptions(window_size=30), ref, 0) is NotImplemented
+    recs = [bamio.parse_record(bamio.pack_record(0, 5, "s", 0, 30, [(CMATCH, 4), (CREF_SKIP, 10), (CMATCH, 4)], "ACGTACGT", [30] * 8)[4:])]
+    assert PE.process_tracks(resolve_reads(recs), 0, 40, 8, PE.EncoderOptions(window_size=16), "A" * 40, 0) is NotImplemented
+    ok = [bamio.parse_record(bamio.pack_record(0, 5, "s", 0, 30, [(CMATCH, 8)], "ACGTACGT", [30] * 8)[4:])]
+    assert PE.process_tracks(resolve_reads(ok), 0, 40, 8, PE.EncoderOptions(window_size=16, min_base_quality=5), "A" * 40, 0) is NotImplemented
+    assert PE.process_tracks(resolve_reads(ok), 0, 40, 30, PE.EncoderOptions(window_size=16), "A" * 40, 0) is None      # POS not covered
