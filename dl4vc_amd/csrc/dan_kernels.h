@@ -111,6 +111,8 @@ struct Segment16Args {
     const int* work_count;
 };
 void launch_segment16(const Segment16Args& a, int n_sites, int precision, int max_wgs, hipStream_t s);
+// plain bf16, one workgroup per row, two workgroups resident per CU (dan_kernels_bf16w.hip)
+void launch_segment16w(const Segment16Args& a, int n_sites, hipStream_t s);
 // Empty-row map: a pileup row whose reads / qual / strand bytes are all zero (padding below the site's coverage) encodes to
 // the same activations as every other such row of its site, through every layer.  row_src[site*R + r] = site*R + (first
 // empty row of the site) for an empty row, site*R + r otherwise; the segment kernels walk only the rows that are their own

@@ -13,6 +13,7 @@
 // re-filled right after their last use.  HBM formats are unchanged (fp32 y / pool / h), so the pooling,
 // highway and FC kernels are shared with the fp32 path.
 #include "dan_kernels.h"
+#include <cstdlib>
 
 namespace dan {
 
@@ -487,6 +488,8 @@ void launch_segment16(const Segment16Args& a0, int n_sites, int precision, int m
     Segment16Args a = a0;
     a.n_rows = n_sites * a.R;
     const bool persist = a.work_count != nullptr && max_wgs > 0 && max_wgs < a.n_rows;
+    static const int form = getenv("DAN_BF16_FORM") ? atoi(getenv("DAN_BF16_FORM")) : 4;
+    if (precision == 2 && !persist && form == 4) { launch_segment16w(a0, n_sites, s); return; }
     const dim3 grid((unsigned)(persist ? max_wgs : a.n_rows)), blk(SEG_THREADS);
     if (persist) {
         if (precision == 1) hipLaunchKernelGGL((segment16_kernel<true, 13, true>), grid, blk, 0, s, a);
