@@ -398,3 +398,37 @@ def test_read_by_read_builder_equals_the_pinned_column_builder():
     ok = [bamio.parse_record(bamio.pack_record(0, 5, "s", 0, 30, [(CMATCH, 8)], "ACGTACGT", [30] * 8)[4:])]
     assert PE.process_tracks(resolve_reads(ok), 0, 40, 8, PE.EncoderOptions(window_size=16, min_base_quality=5), "A" * 40, 0) is NotImplemented
     assert PE.process_tracks(resolve_reads(ok), 0, 40, 30, PE.EncoderOptions(window_size=16), "A" * 40, 0) is None      # POS not covered
+
+
+def test_bgzf_layer_against_pythons_gzip(tmp_path):
+    """BGZF is a series of gzip members: Python's own gzip module (an independent inflater + CRC check) must read what
+    ``BamWriter`` wrote, byte for byte what ``BgzfReader`` returns, and the file must end with the 28-byte EOF marker block."""
+    import gzip as gz
+    p = str(tmp_path / "g.bam")
+    rng = np.random.default_rng(4)
+    with BamWriter(p, [("c", 100000)]) as w:
+        for i, s in enumerate(np.sort(rng.integers(0, 90000, 2500))):
+            w.write(0, int(s), "r%d" % i, 0, 30, [(CMATCH, 100)], "".join(rng.choice(list("ACGT"), 100)), rng.integers(0, 42, 100).tolist())
+    raw = open(p, "rb").read()
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    plain = gz.open(p, "rb").read()
+    assert plain[:4] == b"BAM\x01"
+    r = bamio.BgzfReader(p)
+    mine = r.read(len(plain) + 10)
+    r.close()
+    assert mine == plain
+    # and the records parsed from gzip's bytes are the ones BamFile yields
+    l_text = struct.unpack_from("<i", plain, 4)[0]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", plain, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", plain, o)[0]
+        o += 4 + l_name + 4
+    names = []
+    while o < len(plain):
+        size = struct.unpack_from("<i", plain, o)[0]
+        names.append(bamio.parse_record(plain[o + 4:o + 4 + size]).name)
+        o += 4 + size
+    with BamFile(p) as bam:
+        assert [x.name for x in bam] == names and len(names) == 2500
