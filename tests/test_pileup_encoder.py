@@ -432,3 +432,78 @@ def test_bgzf_layer_against_pythons_gzip(tmp_path):
         o += 4 + size
     with BamFile(p) as bam:
         assert [x.name for x in bam] == names and len(names) == 2500
+
+
+def _naive_resolution(cigar):
+    """Base-by-base walk of a CIGAR, written independently of ReadTrack: per reference offset (qpos, is_del, is_skip) and the
+    indel reported on the last column before an insertion / deletion run."""
+    cols = []                        # [qpos, is_del, is_skip, indel]
+    y = 0
+    expanded = [op for op, l in cigar for _ in range(l)]
+    i = 0
+    while i < len(expanded):
+        op = expanded[i]
+        if op in (CMATCH, 7, 8):
+            cols.append([y, False, False, 0])
+            y += 1
+        elif op in (CDEL, CREF_SKIP):
+            cols.append([y, True, op == CREF_SKIP, 0])
+        elif op in (CINS, CSOFT_CLIP):
+            y += 1
+        i += 1
+    # indels: look at what follows each reference-consuming run in the op list
+    ref_ops = (CMATCH, 7, 8, CDEL, CREF_SKIP)
+    x = 0
+    for k, (op, l) in enumerate(cigar):
+        if op in ref_ops:
+            x += l
+            if k + 1 < len(cigar):
+                nxt = [o for o, _ in cigar[k + 1:]]
+                lens = [n for _, n in cigar[k + 1:]]
+                v = 0
+                if nxt[0] == CDEL and op != CDEL:
+                    j = 0
+                    while j < len(nxt) and nxt[j] == CDEL:
+                        v -= lens[j]
+                        j += 1
+                elif nxt[0] == CINS:
+                    j = 0
+                    while j < len(nxt) and nxt[j] in (CINS, CPAD):
+                        v += lens[j] if nxt[j] == CINS else 0
+                        j += 1
+                elif nxt[0] == CPAD and len(nxt) > 1:
+                    j = 1
+                    while j < len(nxt) and nxt[j] not in ref_ops:
+                        v += lens[j] if nxt[j] == CINS else 0
+                        j += 1
+                cols[x - 1][3] = v
+    return cols
+
+
+def test_cigar_resolution_against_a_naive_walk():
+    from dl4vc_amd.pileup import ReadTrack
+    rng = np.random.default_rng(77)
+    ops_mid = [CMATCH, CINS, CDEL, CREF_SKIP, CPAD, 7, 8]
+    for trial in range(400):
+        cigar = []
+        if rng.random() < 0.3:
+            cigar.append((CHARD_CLIP, int(rng.integers(1, 5))))
+        if rng.random() < 0.4:
+            cigar.append((CSOFT_CLIP, int(rng.integers(1, 9))))
+        cigar.append((CMATCH, int(rng.integers(1, 12))))
+        for _ in range(int(rng.integers(0, 7))):
+            op = int(rng.choice(ops_mid))
+            if cigar[-1][0] == op:
+                continue
+            cigar.append((op, int(rng.integers(1, 6))))
+        if cigar[-1][0] not in (CMATCH, 7, 8):
+            cigar.append((CMATCH, int(rng.integers(1, 9))))
+        if rng.random() < 0.4:
+            cigar.append((CSOFT_CLIP, int(rng.integers(1, 6))))
+        qlen = sum(l for op, l in cigar if op in (CMATCH, CINS, CSOFT_CLIP, 7, 8))
+        rec = bamio.BamRecord(0, 100, 30, 0, "t", tuple(cigar), "A" * qlen, np.full(qlen, 30, np.uint8))
+        t = ReadTrack(rec)
+        want = _naive_resolution(cigar)
+        assert t.end - t.start == len(want) == rec.reference_end - rec.pos, cigar
+        got = [[int(t.qpos[i]), bool(t.is_del[i]), bool(t.is_refskip[i]), int(t.indel[i])] for i in range(len(want))]
+        assert got == want, (cigar, got, want)
