@@ -488,7 +488,8 @@ void launch_segment16(const Segment16Args& a0, int n_sites, int precision, int m
     Segment16Args a = a0;
     a.n_rows = n_sites * a.R;
     const bool persist = a.work_count != nullptr && max_wgs > 0 && max_wgs < a.n_rows;
-    static const int form = getenv("DAN_BF16_FORM") ? atoi(getenv("DAN_BF16_FORM")) : 4;
+    const char* form_env = getenv("DAN_BF16_FORM");           // 8: the eight-wave kernel for plain bf16 too (A/B runs, tests)
+    const int form = form_env ? atoi(form_env) : 4;
     if (precision == 2 && !persist && form == 4) { launch_segment16w(a0, n_sites, s); return; }
     const dim3 grid((unsigned)(persist ? max_wgs : a.n_rows)), blk(SEG_THREADS);
     if (persist) {

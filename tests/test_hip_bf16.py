@@ -75,3 +75,42 @@ def test_fp32_rejects_long_window_but_bf16_accepts():
     with pytest.raises(RuntimeError, match="length"):
         DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16X3))
     DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16)).close()
+
+
+@pytest.mark.parametrize("case", ["dan_small", "dan_var_pool24", "dan_var_l5res2", "dan_var_cfinal", "dan_var_nohw", "dan_var_nobn"])
+def test_plain_bf16_two_workgroup_form_is_bit_identical_to_the_eight_wave_form(case, monkeypatch):
+    """precision 2 runs dan_kernels_bf16w.hip (four waves, two workgroups per CU, two channel passes) when every row is computed;
+    DAN_BF16_FORM=8 selects the eight-wave kernel.  Same arithmetic in the same order: every output bit agrees, on the
+    structural variants (pool layers, a residual layer opening a segment, c_final != c_init, no highway, no BatchNorm)."""
+    spec, w, inp, out = load_case(case)
+    res = {}
+    for form in ("4", "8"):
+        monkeypatch.setenv("DAN_BF16_FORM", form)
+        net = DanNet(_cfg(spec, PRECISION_BF16)).load_state_dict(w)
+        res[form] = net.forward_u8(*input_tuple(inp), aux=True)
+        net.close()
+    for k in res["4"]:
+        assert np.array_equal(res["4"][k], res["8"][k]), (case, k)
+    scale = max(1.0, float(np.abs(out["vt_logits"]).max()))
+    assert np.abs(res["4"]["vt_logits"] - out["vt_logits"]).max() < 0.05 * scale
+
+
+def test_plain_bf16_forms_agree_at_301_columns_and_with_empty_row_skipping(monkeypatch):
+    cfg = DanConfig(reads=20, length=301, precision=PRECISION_BF16)
+    sd = random_state_dict(cfg, seed=5)
+    batch = synth.make_sites(5, reads=20, length=301, seed=6)
+    res = {}
+    for form in ("4", "8"):
+        monkeypatch.setenv("DAN_BF16_FORM", form)
+        net = DanNet(cfg).load_state_dict(sd)
+        res[form] = net.forward_u8(*batch.arrays(), aux=True)
+        net.close()
+    for k in res["4"]:
+        assert np.array_equal(res["4"][k], res["8"][k]), k
+    import dataclasses
+    monkeypatch.setenv("DAN_BF16_FORM", "4")
+    net = DanNet(dataclasses.replace(cfg, skip_empty_rows=True)).load_state_dict(sd)      # (the row-list forms stay on the eight-wave kernel)
+    skip = net.forward_u8(*batch.arrays(), aux=True)
+    net.close()
+    for k in skip:
+        assert np.array_equal(skip[k], res["4"][k]), k
