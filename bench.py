@@ -105,7 +105,7 @@ def bench_train(args):
     the FC-side bucket under the convolution layers' backward; replaces nn.DataParallel, main.py:117); weak scaling."""
     import torch
     from dl4vc_amd.config import DanConfig
-    from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights, GradientExchange
+    from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights, GradientExchange, base_class_weight_sums
     from dl4vc_amd import synth
     from dl4vc_amd.synth import random_state_dict
     rank = int(os.environ.get("RANK", "0"))
@@ -141,8 +141,14 @@ def bench_train(args):
     exchange = GradientExchange(dist, world) if world > 1 else None
     (o0, n0), (o1, n1) = tr.grad_buckets()
 
+    sums_dev = "cuda" if backend == "nccl" else "cpu"
+
     def step(i):
         if world > 1:
+            g = torch.tensor(base_class_weight_sums(tg), dtype=torch.float64, device=sums_dev)     # full-batch loss normalisers
+            dist.all_reduce(g)
+            g = g.cpu().numpy() / world
+            tr.set_global_batch(g[0], g[1], g[2])
             tr.backward_begin(planes, tg, seed=i)
             tr.wait_bucket(0)
             exchange.start(grad[o0:o0 + n0])                  # FC stack + heads: exchanged under the conv layers' backward

@@ -152,6 +152,10 @@ struct LossArgs {
     float* losses;                          // [8]: loss, bin, vt, af, cov, vb, vr, (unused)
     uint8_t* close;                         // [B][2]: bin_close, vt_close
     float* site_terms;                      // [B][8] scratch
+    // data parallelism: the normalisers of the FULL batch divided by the number of ranks (0 = this rank's own), so that the
+    // average of the ranks' gradients is the full-batch gradient nn.DataParallel computes (main.py:117)
+    float mean_sites;                       // replaces B in the .mean() terms
+    float ce_den[2];                        // replace sum_b w[y_b] of the two weighted cross-entropies (var base, ref base)
 };
 void launch_heads_loss(const LossArgs& a, hipStream_t s);
 // dhidden[b][k] = sum_j dlogits[b][j] wh[j][k];  gwh[j][k] = sum_b dlogits[b][j] hidden[b][k];  gbh[j] = sum_b dlogits[b][j]

@@ -1383,8 +1383,8 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(LossArgs a, float* site
         red[tid][0] = sum;
     }
     __syncthreads();
-    const float wb_tot = red[0][0], wr_tot = red[1][0];
-    const float invB = 1.f / (float)a.B;
+    const float wb_tot = a.ce_den[0] > 0.f ? a.ce_den[0] : red[0][0], wr_tot = a.ce_den[1] > 0.f ? a.ce_den[1] : red[1][0];
+    const float invB = 1.f / (a.mean_sites > 0.f ? a.mean_sites : (float)a.B);
     const float pw2[2] = {a.fp_weight / (a.fp_weight + 1.f), 1.f / (a.fp_weight + 1.f)};
     const float pw3[3] = {a.fp_weight / (a.fp_weight + 2.f), 1.f / (a.fp_weight + 2.f), 1.f / (a.fp_weight + 2.f)};
     for (int b = tid; b < a.B; b += 256) {

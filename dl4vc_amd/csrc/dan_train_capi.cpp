@@ -103,6 +103,7 @@ struct dan_trainer {
     // dan_train_backward_begin / _end: the step in flight and the event behind which the FC-side gradients are final
     bool pending = false;
     hipEvent_t ev_tail = nullptr;
+    float dp_mean_sites = 0.f, dp_ce_den[2] = {0.f, 0.f};     // dan_train_set_global_batch: for the next backward only
 };
 
 namespace {
@@ -560,6 +561,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
         a.fp_weight = hp.fp_train_weight; a.binary_weight = hp.binary_weight; a.aux_weight = hp.aux_weight;
         a.aux_bases_weight = hp.aux_bases_weight; a.aux_allele_weight = hp.aux_allele_weight;
         a.logits = t->d_logits; a.dlogits = t->d_dlogits; a.losses = t->d_losses; a.close = t->d_close; a.site_terms = t->d_site_terms;
+        a.mean_sites = t->dp_mean_sites; a.ce_den[0] = t->dp_ce_den[0]; a.ce_den[1] = t->dp_ce_den[1];
+        t->dp_mean_sites = 0.f; t->dp_ce_den[0] = t->dp_ce_den[1] = 0.f;
         launch_heads_loss(a, s);
     }
 
@@ -706,6 +709,15 @@ int dan_train_backward(dan_trainer_t* t, const uint8_t* reads, const uint8_t* qu
     const int rc = dan_train_backward_begin(t, reads, qual, strand, ref, ref_mask, var_mask, n_sites, tg, dropout_masks, seed);
     if (rc) return rc;
     return dan_train_backward_end(t, losses, close);
+}
+
+int dan_train_set_global_batch(dan_trainer_t* t, float sites_per_rank, float vb_weight_per_rank, float vr_weight_per_rank) {
+    if (!t || !t->finalized) return DAN_ERR_STATE;
+    if (t->pending) return failt(t, DAN_ERR_STATE, "dan_train_set_global_batch with a step in flight");
+    if (sites_per_rank < 0.f || vb_weight_per_rank < 0.f || vr_weight_per_rank < 0.f)
+        return failt(t, DAN_ERR_INVALID_ARG, "dan_train_set_global_batch: negative normaliser");
+    t->dp_mean_sites = sites_per_rank; t->dp_ce_den[0] = vb_weight_per_rank; t->dp_ce_den[1] = vr_weight_per_rank;
+    return DAN_OK;
 }
 
 int dan_train_grad_bucket(dan_trainer_t* t, int32_t bucket, int64_t* offset, int64_t* count) {

@@ -23,7 +23,7 @@ from .model import normalise_state_dict
 TRAIN_SYMBOLS = ("dan_train_create", "dan_train_set_tensor", "dan_train_finalize", "dan_train_destroy", "dan_train_last_error",
                  "dan_train_backward", "dan_train_apply", "dan_train_step", "dan_train_set_lr", "dan_train_grad_buffer", "dan_train_get_tensor",
                  "dan_train_put_tensor", "dan_train_query", "dan_train_backward_begin", "dan_train_backward_end", "dan_train_wait_bucket",
-                 "dan_train_grad_bucket")
+                 "dan_train_grad_bucket", "dan_train_set_global_batch")
 
 LOSS_NAMES = ("loss", "bin", "vt", "af", "cov", "vb", "vr")
 
@@ -86,6 +86,7 @@ def _bind(lib):
     lib.dan_train_backward_end.argtypes = [vp, vp, vp]
     lib.dan_train_wait_bucket.argtypes = [vp, C.c_int32]
     lib.dan_train_grad_bucket.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.dan_train_set_global_batch.argtypes = [vp, C.c_float, C.c_float, C.c_float]
     lib.dan_train_apply.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dan_train_step.argtypes = [vp] + planes + [C.c_int64, C.POINTER(_CTargets), C.POINTER(vp), C.c_uint64, vp, vp, C.POINTER(C.c_float)]
     lib.dan_train_set_lr.argtypes = [vp, C.c_float]
@@ -107,6 +108,17 @@ def example_weights(is_snp, hyper: TrainHyper, trust_weight=None) -> np.ndarray:
     if trust_weight is not None:
         w = w * np.asarray(trust_weight, np.float32)
     return w.astype(np.float32)
+
+
+BASE_CLASS_WEIGHT = np.array([0.001, 1., 1., 1., 1., 1., 0.001, 0.001, 1., 0.001])      # trainer.py:312-313
+
+
+def base_class_weight_sums(targets: Mapping) -> np.ndarray:
+    """[sites, sum of class weights of var_base_enum, of var_ref_enum] of this rank's share of a batch: summed over the ranks
+    and divided by their number these are the arguments of ``DanTrainer.set_global_batch``."""
+    vb = np.asarray(targets["var_base_enum"]).astype(np.int64).reshape(-1)
+    vr = np.asarray(targets["var_ref_enum"]).astype(np.int64).reshape(-1)
+    return np.array([len(vb), BASE_CLASS_WEIGHT[np.minimum(vb, 9)].sum(), BASE_CLASS_WEIGHT[np.minimum(vr, 9)].sum()], np.float64)
 
 
 def average_gradients(grad, world_size: int, all_reduce) -> None:
@@ -309,6 +321,11 @@ class DanTrainer:
         self._check(self.lib.dan_train_backward_end(self._h, losses.ctypes.data_as(C.c_void_p), close.ctypes.data_as(C.c_void_p)),
                     "dan_train_backward_end")
         return self._outputs(losses, close)
+
+    def set_global_batch(self, sites_per_rank: float, vb_weight_per_rank: float, vr_weight_per_rank: float) -> None:
+        """Full-batch normalisers / ranks for the next backward (``base_class_weight_sums`` gives the local sums to all-reduce)."""
+        self._check(self.lib.dan_train_set_global_batch(self._h, float(sites_per_rank), float(vb_weight_per_rank), float(vr_weight_per_rank)),
+                    "dan_train_set_global_batch")
 
     def grad_buckets(self):
         """[(offset, count)] of bucket 0 and bucket 1 in the flat gradient buffer (``grad_tensor``): together they tile it."""

@@ -23,7 +23,7 @@ import numpy as np
 
 from .hdf5io import CandidateFile
 from .train_data import assemble_training_batch, read_indices, BatchPrefetcher, EasyExampleSampler   # noqa: F401
-from .train import TrainHyper, average_gradients, GradientExchange
+from .train import TrainHyper, average_gradients, GradientExchange, base_class_weight_sums
 
 COVERAGE_SCALE_FACTOR = 1.0 / 100.0                       # trainer.py:61
 BASE_CLASS_WEIGHT = np.array([0.001, 1., 1., 1., 1., 1., 0.001, 0.001, 1., 0.001])     # trainer.py:312-313
@@ -114,11 +114,24 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
         stream = prefetcher.batches((m for _, _, m in plan), **kwargs)
     else:
         stream = (assemble_training_batch(read_indices(source, m), m, **kwargs) for _, _, m in plan)
+    def global_normalisers(batch):
+        """Full-batch loss normalisers / ranks (one tiny all-reduce): with them the average of the ranks' gradients is the
+        full-batch gradient nn.DataParallel computes, also for unequal shards (include/dl4vc_dan_train.h)."""
+        import torch
+        dist = exchange.dist
+        t = torch.tensor(base_class_weight_sums(batch.targets), dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        g = t.cpu().numpy() / world
+        trainer.set_global_batch(g[0], g[1], g[2])
+
     split = hasattr(trainer, "backward_begin")
     feed = zip(plan, stream)
     nxt = next(feed, None)
     while nxt is not None:
         (b, lo, mine), batch = nxt
+        if world > 1 and exchange is not None and hasattr(trainer, "set_global_batch"):
+            global_normalisers(batch)
         if split:
             # enqueue the step, then take delivery of the next batch (worker hand-over, unpickling) while the device works
             trainer.backward_begin(batch.planes(), batch.targets, seed=reads_seed + epoch)

@@ -87,6 +87,14 @@ int dan_train_wait_bucket(dan_trainer_t* t, int32_t bucket);
 int dan_train_backward_end(dan_trainer_t* t, float* losses, uint8_t* close);
 int dan_train_grad_bucket(dan_trainer_t* t, int32_t bucket, int64_t* offset, int64_t* count);
 
+/* Data parallelism, exactness: nn.DataParallel (main.py:117) computes every loss on the gathered FULL batch, so its .mean()
+ * terms divide by the full batch size and its two weighted cross-entropies (trainer.py:312-313) by the full batch's sum of
+ * class weights.  For the average of the ranks' gradients to equal that gradient also when the shards differ, a rank passes,
+ * for the NEXT dan_train_backward[_begin] only, those normalisers divided by the number of ranks: full-batch sites / ranks,
+ * and (sum over the full batch of the base-class weight of var_base_enum, resp. var_ref_enum) / ranks.  Zero = the rank's
+ * own (the single-GPU behaviour).  The class weights are 0.001 for tokens 0, 6, 7, 9 and 1 otherwise. */
+int dan_train_set_global_batch(dan_trainer_t* t, float sites_per_rank, float vb_weight_per_rank, float vr_weight_per_rank);
+
 /* clip_grad_norm_ + Adam on the gradients currently on the device; advances the step counter.  grad_norm (may be NULL)
  * receives the total 2-norm before clipping. */
 int dan_train_apply(dan_trainer_t* t, float* grad_norm);

@@ -297,3 +297,54 @@ def test_random_structures_train_step_against_float64_oracle(seed):
     against the training oracle in float64 (1e-4 of the tensor's max plus twice the fp32 oracle's own distance from it).
     tools/fuzz_train.py runs the same check over a wider seed range."""
     run_random_train_case(seed)
+
+
+def test_data_parallel_average_equals_the_full_batch_gradient():
+    """nn.DataParallel (main.py:117) computes the losses on the gathered full batch.  With the full-batch normalisers handed to
+    every rank (dan_train_set_global_batch) the average of the per-rank gradients IS the full-batch gradient -- here for UNEQUAL
+    shards (3 + 1 sites) of a network without BatchNorm (BatchNorm statistics are per replica in DataParallel too, so with it the
+    two differ by design); without the normalisers the weighted cross-entropies and the .mean() terms are off."""
+    from dl4vc_amd.train import base_class_weight_sums
+    spec, hyper, w, steps, *_ = load_train_case("train_var_nobn")
+    cfg, hp, st = cfg_from(spec), hyper_from(hyper), steps[0]
+    B = len(st["vcfrec"])
+    assert B == 4 and not cfg.use_bn
+    keys = list(st["grad"])
+    fc_idx = sorted({int(q.split(".")[1]) for q in keys if q.startswith("conv2hidden.")})
+
+    def grads(tr):
+        out = {}
+        for k in keys:
+            name = k if not k.startswith("conv2hidden.") else "fc.%d.%s" % (fc_idx.index(int(k.split(".")[1])), k.split(".")[2])
+            out[k] = tr.tensor("grad:" + name, st["grad"][k].shape).astype(np.float64)
+        return out
+
+    full = DanTrainer(cfg, hp, max_batch=B).load_state_dict(w)
+    full.backward(st["planes"], st["targets"], dropout_masks=st["masks"] if hp.dropout > 0 else None)
+    want = grads(full)
+    full.close()
+    shares = [(0, 3), (3, 4)]
+    world = len(shares)
+    total = base_class_weight_sums(st["targets"])
+    for exact in (True, False):
+        acc = {k: np.zeros_like(v, np.float64) for k, v in want.items()}
+        for lo, hi in shares:
+            tr = DanTrainer(cfg, hp, max_batch=4).load_state_dict(w)
+            planes = [p[lo:hi] for p in st["planes"]]
+            tg = {k: np.asarray(v)[lo:hi] for k, v in st["targets"].items()}
+            masks = [m[lo:hi] for m in st["masks"]] if hp.dropout > 0 else None
+            if exact:
+                tr.set_global_batch(total[0] / world, total[1] / world, total[2] / world)
+            tr.backward(planes, tg, dropout_masks=masks)
+            for k, g in grads(tr).items():
+                acc[k] += g / world
+            tr.close()
+        # (the embedding gradient is scaled by the token frequencies of the mini-batch a replica sees -- scale_grad_by_freq,
+        # model.py:145 -- so DataParallel's own embedding gradient is the sum over replicas of shard-scaled gradients, which is
+        # what the ranks' average gives and NOT what one full-batch backward gives: it is left out of this comparison)
+        errs = {k: float(np.abs(acc[k] - want[k]).max()) / max(float(np.abs(want[k]).max()), 1e-30) for k in want if k != "embeddings.weight"}
+        worst = max(errs.values())
+        if exact:
+            assert worst < 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        else:
+            assert worst > 1e-3, worst                            # (equal-weight averaging of unequal shards is not the full-batch mean)
