@@ -10,9 +10,9 @@ functions
     handle_ended_sequences, center_image_on_column, trim_empty_rows, center_image_on_row_window
 
 and executes exactly those definitions.  The per-column loop of ``process_location`` (:906-1118) and the crop / pad step of
-``process_locations_chunk`` (:720-838) take pysam objects and are transcribed below around those functions (``drive_columns``,
-``crop_and_pad``): every array operation on the images is the reference's own code, the bookkeeping between the calls is a
-transcription.  Inputs are synthetic pileup columns (read strings, qualities, read ids, reference bases) of simulated reads
+``process_locations_chunk`` (:720-838) take pysam objects; ``drive_columns`` and ``crop_and_pad`` below restate the bookkeeping
+between the calls (row table, column cursor, growth, cropping offsets) around those functions: every array operation on the
+images is the reference's own code.  Inputs are synthetic pileup columns (read strings, qualities, read ids, reference bases) of simulated reads
 with substitutions, insertions, deletions, soft clips, both strands and duplicated read ids; they are stored in the fixture,
 so the test needs neither this script nor the reference.
 
@@ -53,101 +53,69 @@ def reference_namespace():
 
 
 def drive_columns(R, columns, center_position, window_size, max_insert_length, max_insert_length_variant):
-    """process_location (:846-1118) with the pysam calls replaced by the prepared columns."""
-    args = SimpleNamespace(save_q_scores=True, save_strand=True, debug=False)
-    MAX_INSERT_LENGTH = max_insert_length
-    MAX_INSERT_VARIANT = max(max_insert_length_variant, MAX_INSERT_LENGTH)
-    window_size += 2
-    max_reads, read_window = 1200, 3 * window_size
-    alignment_image = np.full((max_reads, read_window), R.base_enum['pad'], dtype=np.uint8)
-    read_quality_image = np.full(alignment_image.shape, 0, dtype=np.uint8)
-    strand_image = np.full(alignment_image.shape, 0, dtype=np.uint8)
-    MAX = 1000
-    idx, prev_col_offset, col_offset, local_max_col_offset = 0, 0, 1, 0
-    read_row_dict, reads_offset, col_reference_map = {}, 0, {}
-    for c in columns:
-        if idx > MAX:
+    """What process_location (:846-1118) does between its pysam calls, around the reference's own image functions: three
+    planes that grow on demand, a row per read id, a column cursor that advances by one plus the column's insertion width."""
+    flags = SimpleNamespace(save_q_scores=True, save_strand=True, debug=False)
+    cap_variant = max(max_insert_length_variant, max_insert_length)
+    planes = [np.full((1200, 3 * (window_size + 2)), fill, dtype=np.uint8) for fill in (R.base_enum['pad'], 0, 0)]   # bases, quality, strand
+    rows, n_done = {}, 0
+    cursor, previous = 1, 0
+    where = {}                                                   # column number -> (image column, reference position, reference base)
+    for number, c in enumerate(columns):
+        if number > 1000:
             break
-        (query_seq_bases, query_seq_inserts) = R.decode_query_sequences(c["sequences"])
-        assert len(query_seq_bases) == len(c["ids"]), "mismatch between pileups & sequences"
-        query_qualities = c["qualities"]
-        query_seq_ids = c["ids"]
-        min_row_size = len(read_row_dict) + reads_offset + len(query_seq_ids) + 1
-        min_col_size = col_offset + MAX_INSERT_VARIANT + max(10, MAX_INSERT_VARIANT)
-        alignment_image = R.resize_alignment_image(min_row_size, min_col_size, alignment_image)
-        read_quality_image = R.resize_alignment_image(min_row_size, min_col_size, read_quality_image)
-        strand_image = R.resize_alignment_image(min_row_size, min_col_size, strand_image)
-        for i, name in enumerate(query_seq_ids):
-            if not (name in read_row_dict.keys()):
-                read_row_dict[name] = len(read_row_dict) + reads_offset
-        is_variant = (c["reference_pos"] == center_position - 1)
-        local_max_col_offset = R.add_bases_to_alignment_image(
-            query_seq_bases, query_seq_inserts, query_seq_ids, alignment_image, col_offset, prev_col_offset, read_row_dict,
-            query_qualities=query_qualities, read_quality_image=read_quality_image, strand_image=strand_image,
-            MAX_INSERT_LENGTH=(MAX_INSERT_VARIANT if is_variant else MAX_INSERT_LENGTH), args=args)
-        (read_row_dict, reads_offset, finished_rows) = R.handle_ended_sequences(
-            query_seq_bases, query_seq_ids, alignment_image, read_row_dict, reads_offset, col_offset, local_max_col_offset,
-            query_qualities=query_qualities, read_quality_image=read_quality_image, strand_image=strand_image, args=args)
-        col_reference_map[idx] = (col_offset, c["reference_pos"], c["ref_base"])
-        idx += 1
-        prev_col_offset = col_offset
-        col_offset = col_offset + 1 + local_max_col_offset
-        local_max_col_offset = 0
-    for row_num in range(strand_image.shape[0]):
-        num_pads = np.sum(strand_image[row_num, :] == R.STRAND_PAD)
-        if num_pads == 0:
-            continue
-        row_nopad = strand_image[row_num, :] * ~(strand_image[row_num, :] == R.STRAND_PAD)
-        strand_value = max(row_nopad)
-        if strand_value == 0:
-            strand_value = R.STRAND_UPPER
-        strand_image[row_num, :][strand_image[row_num, :] == R.STRAND_PAD] = strand_value
-    n = len(read_row_dict) + reads_offset
-    image_sample = alignment_image[:n, :col_offset + 1]
-    center_index = -1
-    for i in col_reference_map:
-        if int(col_reference_map[i][1]) == center_position - 1:
-            center_index = col_reference_map[i][0]
-            break
-    if center_index == -1:
+        bases, inserts = R.decode_query_sequences(c["sequences"])
+        assert len(bases) == len(c["ids"]), "mismatch between pileups & sequences"
+        need = (len(rows) + n_done + len(c["ids"]) + 1, cursor + cap_variant + max(10, cap_variant))
+        planes = [R.resize_alignment_image(need[0], need[1], p) for p in planes]
+        for read_id in c["ids"]:
+            if read_id not in rows:
+                rows[read_id] = len(rows) + n_done
+        cap = cap_variant if c["reference_pos"] == center_position - 1 else max_insert_length
+        widest = R.add_bases_to_alignment_image(bases, inserts, c["ids"], planes[0], cursor, previous, rows, MAX_INSERT_LENGTH=cap,
+                                                query_qualities=c["qualities"], read_quality_image=planes[1], strand_image=planes[2], args=flags)
+        rows, n_done, _ = R.handle_ended_sequences(bases, c["ids"], planes[0], rows, n_done, cursor, widest, query_qualities=c["qualities"],
+                                                   read_quality_image=planes[1], strand_image=planes[2], args=flags)
+        where[number] = (cursor, c["reference_pos"], c["ref_base"])
+        previous, cursor = cursor, cursor + 1 + widest
+    # a deletion carries no strand of its own (:1063-1078): the row's strand, forward when the row has none
+    strand = planes[2]
+    for k in range(strand.shape[0]):
+        unknown = strand[k] == R.STRAND_PAD
+        if unknown.any():
+            known = int((strand[k] * ~unknown).max())
+            strand[k][unknown] = known if known else R.STRAND_UPPER
+    used = len(rows) + n_done
+    centre = next((col for col, ref_pos, _ in where.values() if int(ref_pos) == center_position - 1), -1)
+    if centre == -1:
         return None
-    return image_sample, center_index, col_reference_map, read_quality_image[:n, :col_offset + 1], strand_image[:n, :col_offset + 1]
+    return planes[0][:used, :cursor + 1], centre, where, planes[1][:used, :cursor + 1], planes[2][:used, :cursor + 1]
 
 
 def crop_and_pad(R, result, window_size, max_reads):
-    """process_locations_chunk (:720-838) for one image; None where the reference counts an error."""
-    single_read, center_index, reference_index, quality_read, strand_read = result
-    TOTAL_SINGLE_READS, TOTAL_COLUMNS = max_reads, 2 * window_size + 1
-    reference_bases = np.full(single_read.shape[1], R.base_enum[''], dtype=np.uint8)
-    for k in reference_index.keys():
-        off, ref_pos, ref_base = reference_index[k]
-        reference_bases[off] = R.base_enum[ref_base]
-    (min_col_idx, max_col_idx) = R.center_image_on_column(single_read, center_index, window_size)
-    single_read = single_read[:, min_col_idx:max_col_idx]
-    quality_read = quality_read[:, min_col_idx:max_col_idx]
-    strand_read = strand_read[:, min_col_idx:max_col_idx]
-    single_read = R.trim_empty_rows(single_read, "top")
-    quality_read = R.trim_empty_rows(quality_read, "top")
-    strand_read = R.trim_empty_rows(strand_read, "top")
-    (min_read, max_read) = R.center_image_on_row_window(single_read, TOTAL_SINGLE_READS)
-    single_read = single_read[min_read:max_read, :]
-    num_reads = single_read.shape[0]
-    quality_read = quality_read[min_read:max_read, :]
-    strand_read = strand_read[min_read:max_read, :]
-    if quality_read.shape != single_read.shape or strand_read.shape != single_read.shape or num_reads <= 0:
+    """The per-image part of process_locations_chunk (:720-838) around the reference's centring / trimming functions; None where
+    the reference counts an error."""
+    image, centre, where, quality, strand = result
+    width = 2 * window_size + 1
+    ref_line = np.full(image.shape[1], R.base_enum[''], dtype=np.uint8)
+    for col, _ref_pos, base in where.values():
+        ref_line[col] = R.base_enum[base]
+    lo, hi = R.center_image_on_column(image, centre, window_size)
+    cut = [R.trim_empty_rows(p[:, lo:hi], "top") for p in (image, quality, strand)]       # (each plane by its OWN row sums, as the reference does)
+    first, last = R.center_image_on_row_window(cut[0], max_reads)
+    cut = [p[first:last, :] for p in cut]
+    if cut[1].shape != cut[0].shape or cut[2].shape != cut[0].shape or cut[0].shape[0] <= 0:
         return None
-    reference_bases = reference_bases[min_col_idx:max_col_idx]
-    single_read_pad = np.zeros((TOTAL_SINGLE_READS, TOTAL_COLUMNS), dtype=np.uint8)
-    reference_bases_pad = np.zeros((TOTAL_COLUMNS), dtype=np.uint8)
-    idx_offset = (window_size) - (center_index - min_col_idx)
-    rows = min(TOTAL_SINGLE_READS, single_read.shape[0])
-    single_read_pad[:rows, idx_offset:idx_offset + single_read.shape[1]] = single_read
-    reference_bases_pad[idx_offset:idx_offset + single_read.shape[1]] = reference_bases
-    quality_read_pad = np.zeros((TOTAL_SINGLE_READS, TOTAL_COLUMNS), dtype=np.uint8)
-    quality_read_pad[:rows, idx_offset:idx_offset + single_read.shape[1]] = quality_read
-    strand_read_pad = np.zeros((TOTAL_SINGLE_READS, TOTAL_COLUMNS), dtype=np.uint8)
-    strand_read_pad[:rows, idx_offset:idx_offset + single_read.shape[1]] = strand_read
-    return single_read_pad, reference_bases_pad, min(num_reads, TOTAL_SINGLE_READS), quality_read_pad, strand_read_pad
+    n = min(max_reads, cut[0].shape[0])
+    shift = window_size - (centre - lo)
+    padded = []
+    for p in cut:
+        out = np.zeros((max_reads, width), dtype=np.uint8)
+        out[:n, shift:shift + p.shape[1]] = p
+        padded.append(out)
+    ref_out = np.zeros(width, dtype=np.uint8)
+    ref_out[shift:shift + cut[0].shape[1]] = ref_line[lo:hi]
+    return padded[0], ref_out, n, padded[1], padded[2]
 
 
 # ------------------------------------------------------------------------------------------------------
