@@ -225,3 +225,50 @@ def test_call_variants_sh_from_bam_and_candidate_vcf(tmp_path):
     assert np.abs(got[:, 0] - want["bp"].reshape(-1)).max() < 1e-4 and np.abs(got[:, 1:] - want["vt_prob"][:, :k]).max() < 1e-4
     assert gzip.open(str(out / "called_variants.vcf.gz"), "rt").read().startswith("##fileformat")
     assert os.path.isfile(str(out / "called_variants.vcf.gz.tbi"))
+
+
+def test_direct_exchange_runs_on_rccl_with_the_zero_copy_gradient_buffer(tmp_path):
+    """The direct reduce-scatter / all-gather form of GradientExchange through RCCL itself (one rank: every collective is the
+    identity, but all of them run -- all_to_all_single, all_gather_into_tensor and the all_reduce of the remainder -- on the
+    side stream, on windows of the library's own hipMalloc'ed gradient buffer wrapped zero-copy as a torch tensor)."""
+    script = tmp_path / "one_rank.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1")
+import numpy as np, torch, torch.distributed as dist
+from golden_util import load_train_case
+from test_hip_train import cfg_from, hyper_from
+from dl4vc_amd.train import DanTrainer, GradientExchange
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+spec, hyper, w, steps, *_ = load_train_case("train_small")
+cfg, hp, st = cfg_from(spec), hyper_from(hyper), steps[0]
+tr = DanTrainer(cfg, hp, max_batch=6).load_state_dict(w)
+tr.backward_begin(st["planes"], st["targets"], dropout_masks=st["masks"])
+g = tr.grad_tensor()
+(o0, n0), (o1, n1) = tr.grad_buckets()
+ex = GradientExchange(dist, 1, direct=True)
+ex.world = 1
+tr.wait_bucket(0)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    ex._side = side
+    ex._mean(g[o0:o0 + n0 - 3])          # a window whose length the (one) rank divides ...
+    dist.all_reduce(g[o0 + n0 - 3:o0 + n0])
+out = tr.backward_end()
+with torch.cuda.stream(side):
+    ex._mean(g[o1:o1 + n1])
+ex.finish()
+after = g.clone()
+ref = DanTrainer(cfg, hp, max_batch=6).load_state_dict(w)
+ref.backward(st["planes"], st["targets"], dropout_masks=st["masks"])
+assert torch.equal(after, ref.grad_tensor()), "the exchange changed a one-rank gradient"
+norm = tr.apply()
+assert abs(norm - float(st["grad_norm"])) <= 1e-4 * float(st["grad_norm"])
+dist.destroy_process_group()
+print("ok", out["loss"])
+''' % (ROOT, ROOT))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])
