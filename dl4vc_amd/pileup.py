@@ -28,7 +28,7 @@ alignment and to the rules above.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Iterable, Iterator, List, Optional, Sequence
+from typing import Iterable, Iterator, List, Optional
 
 import numpy as np
 

@@ -11,8 +11,8 @@ bookkeeping.  There is no PyTorch/CPU fallback: construction fails loudly withou
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, asdict
-from typing import Dict, Mapping, Optional, Sequence
+from dataclasses import dataclass
+from typing import Dict, Mapping, Sequence
 
 import numpy as np
 
