@@ -60,6 +60,7 @@ struct dan_handle {
     int n_cus = 0;
     float *d_wc = nullptr, *d_bc = nullptr;
     float *d_feat = nullptr, *d_hid0 = nullptr, *d_hid1 = nullptr;
+    float* d_fc_ws = nullptr;                                  // split-k partial sums of FC1 [2][max_batch][fc0]
     float *d_w0 = nullptr, *d_b0 = nullptr, *d_w1 = nullptr, *d_b1 = nullptr, *d_wh = nullptr, *d_bh = nullptr;
     // staging for the host-pointer entry points
     uint8_t* d_in = nullptr;
@@ -469,6 +470,7 @@ int dan_finalize(dan_t* h) {
     HIPCHK(h, hipMemset(h->d_feat, 0, (size_t)h->max_batch * h->F_stride * sizeof(float)));
     if ((rc = dev_alloc(h, &h->d_hid0, (size_t)h->max_batch * h->n0_stride)) || (rc = dev_alloc(h, &h->d_hid1, (size_t)h->max_batch * n1))) return rc;
     HIPCHK(h, hipMemset(h->d_hid0, 0, (size_t)h->max_batch * h->n0_stride * sizeof(float)));
+    if ((rc = dev_alloc(h, &h->d_fc_ws, (size_t)2 * h->max_batch * h->cfg.fc_sizes[0]))) return rc;
     const size_t in_site = (size_t)3 * R * L + 3 * L;
     if ((rc = dev_alloc(h, &h->d_in, (size_t)h->max_batch * in_site))) return rc;
     if ((rc = dev_alloc(h, &h->d_out, (size_t)h->max_batch * (2 + 3 + 3 + 1 + 22)))) return rc;
@@ -577,7 +579,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
         EventPair ev{};
         int rc = prof_begin(h, "fc", s, &ev); if (rc) return rc;
         launch_fc(h->d_feat, h->F_stride, h->d_w0, h->F_stride, h->d_b0, h->d_hid0, h->n0_stride, nb, c.fc_sizes[0],
-                  (int)h->F_stride, 1, s);
+                  (int)h->F_stride, 1, s, h->d_fc_ws, (long long)2 * h->max_batch * c.fc_sizes[0]);
         launch_fc(h->d_hid0, h->n0_stride, h->d_w1, h->n0_stride, h->d_b1, h->d_hid1, c.fc_sizes[1], nb, c.fc_sizes[1],
                   h->n0_stride, 1, s);
         launch_heads(h->d_hid1, c.fc_sizes[1], h->d_wh, h->d_bh, nb, bin_logits ? bin_logits + mb * 2 : nullptr,

@@ -130,8 +130,9 @@ void launch_highway(const float* h, long long h_layer_stride, const float* wc_pa
                     const float* bc, float* feat, long long feat_stride, int feat_off, int n_sites, int R, int L,
                     int H, int layers, const int* row_src, hipStream_t s);
 // C[M][N] = relu?(A[M][lda] * W[N][ldw]^T + bias)  over K (multiple of 16)
+// ws (may be null): ws_floats >= 2 M N lets a long-k product with few tiles split its k range over two co-resident workgroups
 void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
-               long long ldc, int M, int N, int K, int relu, hipStream_t s);
+               long long ldc, int M, int N, int K, int relu, hipStream_t s, float* ws = nullptr, long long ws_floats = 0);
 // heads + softmax: hidden [B][hid] -> logits/probabilities   (model.py:919-958, trainer.py:609-623)
 void launch_heads(const float* hidden, int hid, const float* wh /*[NHEAD][hid]*/, const float* bh, int B,
                   float* bin_logits, float* vt_logits, float* vt_prob, float* bp, float* aux, hipStream_t s);

@@ -776,18 +776,23 @@ void launch_highway(const float* h, long long hls, const float* wc, long long wc
 // dealt in contiguous runs per XCD (n fastest): an XCD's 32 tiles share 4 row blocks of A and all of W's 8 column blocks,
 // A streams from HBM once and W once per XCD.
 // ------------------------------------------------------------------------------------------------
-constexpr int FC_BM = 128, FC_BN = 128, FC_BK = 32, FC_S = FC_BK + 8, FC_THREADS = 512;
-__global__ __launch_bounds__(FC_THREADS) void fc_kernel(const float* __restrict__ A, long long lda,
-                                                        const float* __restrict__ W, long long ldw,
-                                                        const float* __restrict__ bias, float* __restrict__ C, long long ldc,
-                                                        int M, int N, int K, int relu, int tiles_n, int n_tiles) {
+// FC_S = 36: conflict-free b128 reads (rows land 4 banks apart, 16 rows cover all 64), and two stages of A + W tiles are 72 KB, so
+// TWO workgroups fit a CU: with `ksplit` = 2 every tile's k range is halved between two workgroups that end up co-resident
+// (256 tiles of FC1 = one per CU otherwise), their partial sums go to `ws` and fc_combine_kernel adds them in a fixed order.
+constexpr int FC_BM = 128, FC_BN = 128, FC_BK = 32, FC_S = FC_BK + 4, FC_THREADS = 512;
+__global__ __launch_bounds__(FC_THREADS, 2) void fc_kernel(const float* __restrict__ A, long long lda,
+                                                           const float* __restrict__ W, long long ldw,
+                                                           const float* __restrict__ bias, float* __restrict__ C, long long ldc,
+                                                           int M, int N, int K, int relu, int tiles_n, int n_tiles, int ksplit, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) float sa[2][FC_BM * FC_S], sw[2][FC_BN * FC_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
     // tile of this workgroup (XCD-contiguous order)
-    const int per = (n_tiles + 7) >> 3;
-    const int q = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per || q >= n_tiles) return;
+    const int n_work = n_tiles * ksplit;
+    const int per = (n_work + 7) >> 3;
+    const int qa = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || qa >= n_work) return;
+    const int q = qa / ksplit, part = qa - q * ksplit;          // the parts of one tile are neighbours: same XCD, same L2 lines of C
     const int bm = (q / tiles_n) * FC_BM, bn = (q % tiles_n) * FC_BN;
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
     // staging: thread -> rows (tid >> 3) + 64 i, 16-byte column tid & 7
@@ -819,11 +824,13 @@ __global__ __launch_bounds__(FC_THREADS) void fc_kernel(const float* __restrict_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = splat(0.f);
-    const int KT = (K + FC_BK - 1) / FC_BK;
-    gload(0);
-    sstore(0);
+    const int KT_all = (K + FC_BK - 1) / FC_BK;
+    const int kts = (KT_all + ksplit - 1) / ksplit;
+    const int kt_lo = part * kts, KT = min(KT_all, kt_lo + kts);
+    gload(kt_lo * FC_BK);
+    sstore(kt_lo & 1);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = kt_lo; kt < KT; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < KT) gload((kt + 1) * FC_BK);
         const float* pa = &sa[cur][(wm + r16) * FC_S + kk * 4];
@@ -845,6 +852,22 @@ __global__ __launch_bounds__(FC_THREADS) void fc_kernel(const float* __restrict_
         if (kt + 1 < KT) sstore(cur ^ 1);
         __syncthreads();
     }
+    if (ksplit > 1) {                                            // raw partial sums; bias / ReLU in fc_combine_kernel
+        float* wp = ws + (size_t)part * M * N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = bn + wn + j * 16 + r16;
+            if (n >= N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int m = bm + wm + i * 16 + kk * 4 + jj;
+                    if (m < M) wp[(size_t)m * N + n] = acc[i][j][jj];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = bn + wn + j * 16 + r16;
@@ -864,11 +887,29 @@ __global__ __launch_bounds__(FC_THREADS) void fc_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void fc_combine_kernel(const float* __restrict__ ws, int parts, const float* __restrict__ bias,
+                                                         float* __restrict__ C, long long ldc, int M, int N, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    float v = ws[i];
+    for (int p = 1; p < parts; ++p) v += ws[(size_t)p * M * N + i];
+    v += bias[n];
+    if (relu) v = fmaxf(v, 0.f);
+    C[(size_t)m * ldc + n] = v;
+}
+
 void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
-               long long ldc, int M, int N, int K, int relu, hipStream_t s) {
+               long long ldc, int M, int N, int K, int relu, hipStream_t s, float* ws, long long ws_floats) {
     const int tiles_m = (M + FC_BM - 1) / FC_BM, tiles_n = (N + FC_BN - 1) / FC_BN, n_tiles = tiles_m * tiles_n;
-    const int grid = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(fc_kernel, dim3(grid), dim3(FC_THREADS), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K, relu, tiles_n, n_tiles);
+    // split k in two when there is a workspace, the k range is long and the tiles alone leave CU slots empty
+    const int ksplit = (ws && ws_floats >= 2LL * M * N && K >= 64 * FC_BK && n_tiles <= 384) ? 2 : 1;
+    const int grid = ((n_tiles * ksplit + 7) / 8) * 8;
+    hipLaunchKernelGGL(fc_kernel, dim3(grid), dim3(FC_THREADS), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K, relu, tiles_n, n_tiles, ksplit, ws);
+    if (ksplit > 1) {
+        const long long total = (long long)M * N;
+        hipLaunchKernelGGL(fc_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, ksplit, bias, C, ldc, M, N, relu);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
