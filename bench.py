@@ -29,6 +29,71 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; the bf16x3 path issues 
 PEAK_HBM_GBS = 8000.0
 
 
+def resolve_ranks(args, argv):
+    """--gpus N is a promise about how many ranks take part; it is kept here or the run fails.
+
+    * WORLD_SIZE unset, N == 1: this process is the job.
+    * WORLD_SIZE unset, N > 1: this process has not touched the GPU yet (nothing above imports torch.cuda state), so it
+      starts the N ranks itself -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+      ...` as a CHILD process (never an exec) -- relays the child's stdout / stderr (inherited) and exits with its code.
+    * WORLD_SIZE set (the driver's torch.distributed.run launch): it must equal N.
+    Returns (rank, local_rank, world) for a process that is a rank."""
+    import subprocess
+    ws = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if ws is None:
+        if args.gpus == 1:
+            return 0, 0, 1
+        import socket
+        import torch
+        if not os.environ.get("BENCH_FORCE_DEVICE0"):
+            have = torch.cuda.device_count()                 # counts devices without initialising the GPU runtime
+            if have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        sys.stderr.write("[bench launcher] --gpus %d without WORLD_SIZE: starting %d ranks: %s\n" % (args.gpus, args.gpus, " ".join(cmd)))
+        sys.stderr.flush()
+        raise SystemExit(subprocess.call(cmd, env=env))
+    world = int(ws)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a rank count that is not the one running"
+                         % (args.gpus, world))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
+
+
+def bind_device(local_rank, world):
+    """The rank's device; N ranks need N visible devices (BENCH_FORCE_DEVICE0: the one-GPU rehearsal of the tests)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the DAN path has no CPU form")
+    if os.environ.get("BENCH_FORCE_DEVICE0"):
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank with LOCAL_RANK %d of %d, but only %d GPU(s) are visible"
+                         % (local_rank, world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    return local_rank
+
+
+def count_ranks(dist, world, device):
+    """All-reduce of ones: the number of ranks that really took part (`ranks_seen` of the line)."""
+    if dist is None:
+        return 1
+    import torch
+    t = torch.ones(1, device=device, dtype=torch.int64)
+    dist.all_reduce(t)
+    seen = int(t.item())
+    if seen != world:
+        raise SystemExit("bench.py: %d ranks answered the all-reduce, WORLD_SIZE is %d" % (seen, world))
+    return seen
+
+
 def cpu_baseline(cfg, sd, batch, budget_s=20.0, timing=True):
     """The oracle (torch CPU fp32 restatement of the reference's op sequence) on the host cores:
     a bounded sample of the same workload."""
@@ -108,15 +173,9 @@ def bench_train(args):
     from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights, GradientExchange, base_class_weight_sums
     from dl4vc_amd import synth
     from dl4vc_amd.synth import random_state_dict
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the training step has no CPU path")
-    if os.environ.get("BENCH_FORCE_DEVICE0"):
-        local_rank = 0
+    rank, local_rank, world = args.ranks
+    local_rank = bind_device(local_rank, world)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -125,6 +184,11 @@ def bench_train(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    props = torch.cuda.get_device_properties(local_rank)
+    sys.stderr.write("[bench rank %d/%d] pid %d device cuda:%d %s, %d CUs, backend %s (train)\n" %
+                     (rank, world, os.getpid(), local_rank, props.name, props.multi_processor_count, backend if world > 1 else "none"))
+    sys.stderr.flush()
+    ranks_seen = count_ranks(dist, world, torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
     cfg = DanConfig(reads=100, length=args.window, conv_algo=args.conv_algo)
     hp = TrainHyper()
     B = args.train_batch
@@ -186,7 +250,7 @@ def bench_train(args):
         value = B * world * args.steps / elapsed
         achieved = value / world * flops_site / 1e12
         line = {"metric": "training sites/sec (DAN train step, 100 reads x %d bp)" % cfg.length, "value": round(value, 2),
-                "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "unit": "sites/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "one optimisation step (train-mode forward, focal + aux losses, backward, clip, Adam) on %d sites "
@@ -250,6 +314,7 @@ def main():
                     help="compute the all-padding rows of each pileup once per site (bit-identical outputs; off for the headline, "
                          "which computes every row like the reference)")
     args = ap.parse_args()
+    args.ranks = resolve_ranks(args, sys.argv[1:])           # may start the ranks as a child job and exit with its code
     if args.mode == "train":
         return bench_train(args)
 
@@ -259,19 +324,11 @@ def main():
     from dl4vc_amd import synth
     from dl4vc_amd.synth import random_state_dict          # seeded weights of the reference's shapes
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the DAN forward has no CPU path")
+    rank, local_rank, world = args.ranks
     # rehearsal knobs (tests only): several ranks on ONE GPU cannot use RCCL ("duplicate GPU"), so the launch path can
     # be exercised on a one-GPU box with BENCH_FORCE_DEVICE0=1 BENCH_DIST_BACKEND=gloo; the driver's runs use neither
-    if os.environ.get("BENCH_FORCE_DEVICE0"):
-        local_rank = 0
+    local_rank = bind_device(local_rank, world)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -287,6 +344,7 @@ def main():
                       backend if world > 1 else "none"))
     sys.stderr.flush()
 
+    ranks_seen = count_ranks(dist, world, torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
     cfg = DanConfig(reads=args.reads, length=args.window, precision=args.precision, conv_algo=args.conv_algo,
                     skip_empty_rows=args.skip_empty_rows)
     sd = random_state_dict(cfg, seed=0)
@@ -418,12 +476,14 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if cfg.precision == 0 else PEAK_BF16_MFMA_TFLOPS
         line = {
             "metric": "candidate-variants/sec (DAN fwd, %d reads x %d bp)" % (cfg.reads, cfg.length),
-            "value": round(value, 2), "unit": "candidate-variants/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "candidate-variants/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": ("f32", "bf16x3", "bf16")[cfg.precision], "data": "synthetic",
             "config": {"workload": "synthetic %d sites x %d reads x %d bp per GPU per step, DAN production network "
                                    "(7x conv128 dil2, residual 5-7, read-mean after L2, highway 32, FC %d->1024->256), "
-                                   "seeded random weights" % (B, cfg.reads, cfg.length, cfg.feature_width),
+                                   "seeded random weights; `value` = device-resident rate (inputs in HBM before the timed region, "
+                                   "the bench contract); `value_h2d_to_d2h` = SURVEY section 8d's definition (first H2D to last D2H "
+                                   "from pageable host buffers)" % (B, cfg.reads, cfg.length, cfg.feature_width),
                        "sites_per_gpu": B, "reads": cfg.reads, "window": cfg.length, "parallelism": "site-shard x%d" % world,
                        "gflop_per_site": round(cfg.flops_per_site() / 1e9, 3),
                        "skip_empty_rows": bool(cfg.skip_empty_rows),
@@ -448,9 +508,14 @@ def main():
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         line["parity"] = parity
+        # whole-forward rate against the direct-convolution MFMA ceiling of the precision, for both definitions of the metric
+        ceil_sites = peak * 1e12 / cfg.flops_per_site()
+        line["roofline"]["whole_forward_frac"] = round(value / world / ceil_sites, 4)
         if host_path is not None:
             host_path["ratio_to_value"] = round(host_path["value"] / value, 4)
             line["host_path"] = host_path
+            line["value_h2d_to_d2h"] = host_path["value"]
+            line["roofline"]["whole_forward_frac_h2d_to_d2h"] = round(host_path["value"] / ceil_sites, 4)
         print(json.dumps(line), flush=True)
     net.close()
     if dist is not None:

@@ -293,3 +293,27 @@ def torch_default_init(cfg, seed: int = 1, dropout_keys: bool = True) -> Dict[st
     sd["bin_output_weights"] = np.full((1,), 0.1, np.float32)
     sd["vt_output_weights"] = np.full((1,), 0.1, np.float32)
     return sd
+
+
+# ---- labelled candidate records for the training path (main.py --train_file): synthetic sites + truth columns ----
+GT_COLUMN = ("GT:0/1", "GT:1/1", "GT:0/0", "GT:1|0", "GT:0/1", "GT:1/1", "GT:./.", "GT:0|1")
+LABELS = (0, 0, 2, 1, 0, 1, 2, 0)          # {0: TP, 1: FN, 2: FP}  trainer.py:133
+
+
+def make_labelled_records(n_sites: int, reads: int, seed: int):
+    """Candidate records in the converter's schema with a truth column (vcfrec column 11, utils.py:59-70)."""
+    sites = make_sites(n_sites, reads=reads, seed=seed)
+    from .hdf5_schema import record_dtype
+    recs = np.zeros(n_sites, dtype=record_dtype(200, 201))
+    for i in range(n_sites):
+        recs[i]["name"] = ("chr20:%d" % (1000 + 7 * i)).encode()
+        recs[i]["single_reads"][:reads] = sites.reads[i]
+        recs[i]["q-scores"][:reads] = sites.qual[i]
+        recs[i]["strand"][:reads] = sites.strand[i]
+        recs[i]["ref_bases"] = sites.ref[i]
+        recs[i]["num_reads"] = int(sites.num_reads[i])
+        recs[i]["label"] = LABELS[i % len(LABELS)]
+        rec = sites.vcfrec[i] + "\t" + GT_COLUMN[i % len(GT_COLUMN)]
+        assert len(rec) < 128
+        recs[i]["vcfrec"] = rec.encode()
+    return recs

@@ -57,26 +57,7 @@ TRAIN_FLAGS = ("--lr 0.0002 --grad-clip 1.0 --epochs 1 --log-interval 1 --gpus 1
                "--model-bottleneck-size 32 --model_final_layer_dilation 2 --model_middle_layer_dilation 2 "
                "--model_concat_hw_reads --model-highway-single-reads").split()
 
-GT_COLUMN = ("GT:0/1", "GT:1/1", "GT:0/0", "GT:1|0", "GT:0/1", "GT:1/1", "GT:./.", "GT:0|1")
-LABELS = (0, 0, 2, 1, 0, 1, 2, 0)          # {0: TP, 1: FN, 2: FP}  trainer.py:133
-
-
-def make_records(n_sites: int, reads: int, seed: int):
-    """Candidate records in the converter's schema with a truth column (vcfrec column 11, utils.py:59-70)."""
-    sites = synth.make_sites(n_sites, reads=reads, seed=seed)
-    recs = np.zeros(n_sites, dtype=record_dtype(200, 201))
-    for i in range(n_sites):
-        recs[i]["name"] = ("chr20:%d" % (1000 + 7 * i)).encode()
-        recs[i]["single_reads"][:reads] = sites.reads[i]
-        recs[i]["q-scores"][:reads] = sites.qual[i]
-        recs[i]["strand"][:reads] = sites.strand[i]
-        recs[i]["ref_bases"] = sites.ref[i]
-        recs[i]["num_reads"] = int(sites.num_reads[i])
-        recs[i]["label"] = LABELS[i % len(LABELS)]
-        rec = sites.vcfrec[i] + "\t" + GT_COLUMN[i % len(GT_COLUMN)]
-        assert len(rec) < 128
-        recs[i]["vcfrec"] = rec.encode()
-    return recs
+from dl4vc_amd.synth import make_labelled_records as make_records, GT_COLUMN, LABELS      # noqa: E402,F401  (moved: product-side tools use it)
 
 
 def reference_args(save_dir: str, **over):

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""One-off wider sweep of tests/test_hip_parity.py::test_random_structures_all_forms_agree (GPU): python tools/fuzz_structures.py [first] [count]"""
+"""One-off wider sweep of tests/test_hip_parity.py::test_random_structures_all_forms_agree (GPU): python tests/diagnostics/fuzz_structures.py [first] [count]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_hip_parity as T      # noqa: E402

@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """Wider sweep of tests/test_hip_train.py::test_random_structures_train_step_against_float64_oracle (GPU):
-python tools/fuzz_train.py [first] [count].  A case beyond the tolerance is then classified by tools/fuzz_train_masks.py:
+python tests/diagnostics/fuzz_train.py [first] [count].  A case beyond the tolerance is then classified by tests/diagnostics/fuzz_train_masks.py:
 "flip" when the HIP step took a discrete decision (a ReLU mask element, the read that wins the final max) differently from
 the float64 oracle on a value at the fp32 rounding level (< 1e-5 of the tensor's scale), FAILED otherwise."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "diagnostics"))
 import test_hip_train as T      # noqa: E402
 from fuzz_train_masks import decision_differences   # noqa: E402
 

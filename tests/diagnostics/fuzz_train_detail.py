@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Per-tensor view of one tools/fuzz_train.py case (GPU): python tools/fuzz_train_detail.py SEED [SEED...]
+"""Per-tensor view of one tests/diagnostics/fuzz_train.py case (GPU): python tests/diagnostics/fuzz_train_detail.py SEED [SEED...]
 columns: relative error of the HIP gradient vs the float64 oracle, the fp32 oracle's own relative distance, max |g|."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch                    # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Why a tools/fuzz_train.py case differs: the discrete decisions of the HIP step (conv / bottleneck / highway ReLU masks, the
-read that wins the final max) against the float64 oracle's (GPU): python tools/fuzz_train_masks.py SEED [SEED...].
+"""Why a tests/diagnostics/fuzz_train.py case differs: the discrete decisions of the HIP step (conv / bottleneck / highway ReLU masks, the
+read that wins the final max) against the float64 oracle's (GPU): python tests/diagnostics/fuzz_train_masks.py SEED [SEED...].
 A decision that differs on a pre-activation (or a max gap) at the fp32 rounding level is a rounding flip -- it moves the
 gradients of its layer by a whole element, which no fp32 implementation can avoid; one that differs on a large value is a bug."""
 import os
@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch                    # noqa: E402

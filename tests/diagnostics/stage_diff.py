@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """GPU debugging aid: per-stage max error of the HIP path against the oracle (encoded input, every conv
-layer, feature blocks, hidden, scores) for one configuration.  Usage: python tools/stage_diff.py [small|prod]"""
+layer, feature blocks, hidden, scores) for one configuration.  Usage: python tests/diagnostics/stage_diff.py [small|prod]"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dl4vc_amd.config import DanConfig          # noqa: E402
 from dl4vc_amd.model import DanNet              # noqa: E402
 from dl4vc_amd import synth                     # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """GPU debugging aid: per-tensor gradient error of the HIP training step against the float64 training oracle at production
-width, for the direct and the Winograd form of the 3-tap layers.  Usage: python tools/train_diff.py"""
+width, for the direct and the Winograd form of the 3-tap layers.  Usage: python tests/diagnostics/train_diff.py"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dl4vc_amd.config import DanConfig                     # noqa: E402
 from dl4vc_amd.train import DanTrainer, TrainHyper, example_weights   # noqa: E402
 from dl4vc_amd import synth                                # noqa: E402

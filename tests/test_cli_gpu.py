@@ -73,26 +73,36 @@ def test_main_py_inference(tmp_path, gpus):
         assert line.split("\t")[1] == batch.vcfrec[i].split("\t")[1]
 
 
-def test_bench_two_rank_launch_path():
-    """The N > 1 branch of bench.py exactly as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed
-    on a one-GPU box: both ranks on device 0, gloo instead of RCCL for the barrier and the max of the elapsed times (RCCL
-    refuses two ranks on one device).  Sites shard with no data-path collective: main.py:117 / SURVEY.md section 8e."""
-    import json
+def _bench_launch(how, bench_args):
+    """`driver`: exactly as the driver launches N > 1 (torch.distributed.run, one rank per GPU); `self`: plain
+    `python bench.py --gpus 2` with no WORLD_SIZE -- bench.py then starts the ranks itself (resolve_ranks)."""
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, BENCH_FORCE_DEVICE0="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sites", "512", "--steps", "1",
-           "--warmup", "0", "--no-cpu-baseline", "--no-skip-pass"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_FORCE_DEVICE0="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if how == "driver":
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + bench_args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+
+
+@pytest.mark.parametrize("how", ["driver", "self"])
+def test_bench_two_rank_launch_path(how):
+    """The N > 1 branch of bench.py rehearsed on a one-GPU box: both ranks on device 0, gloo instead of RCCL for the
+    barrier and the max of the elapsed times (RCCL refuses two ranks on one device).  Sites shard with no data-path
+    collective: main.py:117 / SURVEY.md section 8e."""
+    import json
+    r = _bench_launch(how, ["--gpus", "2", "--sites", "512", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-skip-pass"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 1
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 1
+    assert ("[bench launcher]" in r.stderr) == (how == "self")
     assert rec["config"]["sites_per_gpu"] == 512 and rec["config"]["parallelism"] == "site-shard x2"
     # whole-job aggregate: both ranks' sites over the max-over-ranks time
     assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 1024) < 1.0
@@ -116,7 +126,7 @@ def test_main_py_training(tmp_path, gpus):
     same sites identically through the inference-only mode.  gpus = 2: two ranks share device 0 and average their gradients
     over gloo (RCCL refuses two ranks on one device) -- the data-parallel path of BASELINE config 4."""
     import torch
-    from oracle.gen_golden_train import make_records
+    from dl4vc_amd.synth import make_labelled_records as make_records
     recs = make_records(16, 100, 900)
     for name in ("train.hdf", "test.hdf"):
         hdf5io.write_candidates(str(tmp_path / name), recs)
@@ -152,24 +162,17 @@ def test_main_py_training(tmp_path, gpus):
     assert again == scored
 
 
-def test_bench_train_two_rank_launch_path():
-    """bench.py --mode train under torch.distributed.run with two ranks (both on device 0, gloo): the data-parallel branch --
-    one all-reduce of the flat gradient buffer per step -- runs before the driver's multi-GPU bench meets it."""
+@pytest.mark.parametrize("how", ["driver", "self"])
+def test_bench_train_two_rank_launch_path(how):
+    """bench.py --mode train with two ranks (both on device 0, gloo): the data-parallel branch -- the flat gradient buffer
+    averaged per step -- runs before the driver's multi-GPU bench meets it."""
     import json
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, BENCH_FORCE_DEVICE0="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--train-batch", "4", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    r = _bench_launch(how, ["--mode", "train", "--gpus", "2", "--train-batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["unit"] == "sites/s" and rec["config"]["sites_per_gpu_per_step"] == 4
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["unit"] == "sites/s" and rec["config"]["sites_per_gpu_per_step"] == 4
     assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 - 8) < 0.01 and np.isfinite(rec["last_step"]["loss"])
 
 

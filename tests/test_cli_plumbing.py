@@ -267,3 +267,21 @@ def test_single_layer_needs_equal_widths():
     DanConfig(layers=1, pool_layers=(), residual_start=0, c_init=16, c_final=16)
     with pytest.raises(UnsupportedModelOption, match="single conv layer"):
         DanConfig(layers=1, pool_layers=(), residual_start=0, c_init=16, c_final=48)
+
+
+def test_bench_rank_count_is_checked_before_anything_runs():
+    """bench.py --gpus N: a WORLD_SIZE that is not N, or fewer visible devices than N, ends the run non-zero instead of
+    printing a line for a rank count that did not run (the reference's only parallel form is nn.DataParallel over the
+    visible devices, main.py:117)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="2"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    for mode in ("infer", "train"):
+        # no WORLD_SIZE: the launcher would start the ranks itself -- but only onto devices that exist (none here)
+        r = subprocess.run([sys.executable, bench, "--mode", mode, "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not r.stdout.strip()

@@ -295,7 +295,7 @@ def test_random_structures_train_step_against_float64_oracle(seed):
     """Seeded random structures (1-7 layers, widths 8-128, pools, residual start, bottleneck 0-32, BatchNorm on/off, input
     planes on/off, dilations 1-4, dropout, loss hyper-parameters): losses, clip norm and every gradient tensor of the HIP step
     against the training oracle in float64 (1e-4 of the tensor's max plus twice the fp32 oracle's own distance from it).
-    tools/fuzz_train.py runs the same check over a wider seed range."""
+    tests/diagnostics/fuzz_train.py runs the same check over a wider seed range."""
     run_random_train_case(seed)
 
 

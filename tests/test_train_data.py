@@ -16,7 +16,7 @@ from dl4vc_amd.train import TrainHyper, average_gradients
 def _records(n_sites, reads, seed):
     """The record array the fixture generator fed to the reference's dataset (oracle/gen_golden_train.py::make_records is
     deterministic; rebuilt here from the same synthetic sites)."""
-    from oracle.gen_golden_train import make_records
+    from dl4vc_amd.synth import make_labelled_records as make_records
     return make_records(n_sites, reads, seed)
 
 
@@ -225,7 +225,7 @@ def test_batch_prefetcher_workers_yield_the_same_batches_in_order(tmp_path):
     yield is what the in-process path assembles, in the order asked, for shuffled and ragged index lists."""
     from dl4vc_amd import hdf5io
     from dl4vc_amd.train_data import BatchPrefetcher, read_indices
-    from oracle.gen_golden_train import make_records
+    from dl4vc_amd.synth import make_labelled_records as make_records
     recs = make_records(24, 20, 900)
     path = str(tmp_path / "train.hdf")
     hdf5io.write_candidates(path, recs)

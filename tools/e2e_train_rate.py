@@ -8,7 +8,7 @@ import numpy as np
 
 if __name__ == "__main__":
     from dl4vc_amd import hdf5io
-    from oracle.gen_golden_train import make_records      # (synthetic labelled records with GT columns; test infrastructure)
+    from dl4vc_amd.synth import make_labelled_records as make_records      # (synthetic labelled records with GT columns; test infrastructure)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     workers = [int(w) for w in sys.argv[2:]] or [0, 5]
     td = tempfile.mkdtemp(prefix="e2e_train_")
