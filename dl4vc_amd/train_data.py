@@ -194,7 +194,12 @@ class EasyExampleSampler:
     draw (one ``permutation`` of the close indices, one ``permutation`` of the merged list)."""
 
     def __init__(self, n_examples: int, close_keep: float = 0.15, holdout: Optional[np.ndarray] = None,
-                 reverse_holdout: bool = False, shuffle: bool = True, rng: Optional[np.random.RandomState] = None):
+                 reverse_holdout: bool = False, shuffle: bool = True, rng: Optional[np.random.RandomState] = None,
+                 plain: bool = False):
+        # plain: main.py:75-77 -- with --close_examples_sample_rate >= 1 the reference builds NO sampler: a plain
+        # DataLoader(shuffle=True) over the whole dataset, which filters nothing (not the close examples, not the blacklist
+        # and -- a quirk kept, with a warning from main.py -- not the held-out chromosomes either)
+        self.plain = bool(plain)
         self.n = int(n_examples)
         self.close_keep = float(close_keep)
         self.close = np.zeros(self.n, bool)
@@ -214,6 +219,9 @@ class EasyExampleSampler:
 
     def epoch(self) -> np.ndarray:
         self.epochs += 1
+        if self.plain:
+            self.epoch_len = self.n
+            return self.rng.permutation(self.n).astype(np.int64)
         if self.reverse_holdout:                                  # dataset.py:706-711: evaluation on the held-out chromosomes only
             order = np.nonzero(~self.close & ~self.blacklist & self.holdout)[0]
         else:

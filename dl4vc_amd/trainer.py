@@ -78,7 +78,9 @@ def eval_losses(out: Dict[str, np.ndarray], targets: Dict[str, np.ndarray], hp: 
 
 # ------------------------------------------------------------------------------------------------
 def split_batch(n: int, rank: int, world: int):
-    """The slice of a batch of ``n`` sites that ``nn.DataParallel``'s scatter (torch.chunk along dim 0) gives replica ``rank``."""
+    """The slice of a batch of ``n`` sites that ``nn.DataParallel``'s scatter (torch.chunk along dim 0) gives replica ``rank``:
+    chunks of ceil(n / world) sites, so a short last batch leaves the LAST replicas without sites (49 sites over 8 replicas:
+    seven chunks of 7) -- DataParallel then simply runs fewer replicas; here such a rank sits the step out (``train_epoch``)."""
     chunk = -(-n // world)
     lo = min(n, rank * chunk)
     return lo, min(n, lo + chunk)
@@ -105,25 +107,51 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
             break
         idx = order[lo:lo + batch_size]
         a, e = split_batch(len(idx), rank, world)
-        if e <= a:
-            raise RuntimeError("batch of %d sites leaves rank %d of %d without work: lower --gpus or raise --batch-size" % (len(idx), rank, world))
-        plan.append((b, lo, idx[a:e]))
-    kwargs = dict(max_reads=cfg.reads, seed=reads_seed, non_snp_train_weight=hyper.non_snp_train_weight,
+        plan.append((b, lo, idx[a:e]))                                 # possibly empty: the rank sits that step out (below)
+    # the read subset of a pileup deeper than max_reads is redrawn every epoch, as the reference's is (dataset.py:274-281
+    # draws from numpy's global generator, which the epoch's shuffles advance); evaluation and inference keep reads_seed
+    draw_seed = reads_seed + epoch * len(source)
+    # dropout: DataParallel's replicas draw independent masks (each its own device generator); fold the rank in
+    drop_seed = (reads_seed + epoch) * world + rank
+    kwargs = dict(max_reads=cfg.reads, seed=draw_seed, non_snp_train_weight=hyper.non_snp_train_weight,
                   keep_candidate_af=keep_candidate_af, use_q=cfg.use_q, use_strand=cfg.use_strand)
+    busy = [m for _, _, m in plan if len(m)]
     if prefetcher is not None:
-        stream = prefetcher.batches((m for _, _, m in plan), **kwargs)
+        made = prefetcher.batches(iter(busy), **kwargs)
     else:
-        stream = (assemble_training_batch(read_indices(source, m), m, **kwargs) for _, _, m in plan)
+        made = (assemble_training_batch(read_indices(source, m), m, **kwargs) for m in busy)
+    stream = (next(made) if len(m) else None for _, _, m in plan)
     def global_normalisers(batch):
         """Full-batch loss normalisers / ranks (one tiny all-reduce): with them the average of the ranks' gradients is the
         full-batch gradient nn.DataParallel computes, also for unequal shards (include/dl4vc_dan_train.h)."""
         import torch
         dist = exchange.dist
-        t = torch.tensor(base_class_weight_sums(batch.targets), dtype=torch.float64,
-                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        sums = base_class_weight_sums(batch.targets) if batch is not None else np.zeros(3)
+        t = torch.tensor(sums, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t)
         g = t.cpu().numpy() / world
-        trainer.set_global_batch(g[0], g[1], g[2])
+        if batch is not None:
+            trainer.set_global_batch(g[0], g[1], g[2])
+
+    def sit_out():
+        """A step in which this rank has no sites (the short last batch of an epoch): DataParallel runs fewer replicas; here
+        the rank contributes a ZERO gradient to the average, takes part in every collective of the step and applies the same
+        update as the others, so the replicas stay identical and nobody waits on a rank that left."""
+        grad = trainer.grad_tensor()
+        grad.zero_()
+        if grad.is_cuda:
+            import torch
+            torch.cuda.synchronize()                                   # the exchange runs on a side stream
+        if exchange is not None:
+            (o0, n0), (o1, n1) = trainer.grad_buckets()
+            exchange.start(grad[o0:o0 + n0])
+            exchange.start(grad[o1:o1 + n1])
+            exchange.finish()
+        else:
+            average_gradients(grad, world, all_reduce)
+        out = {k: 0.0 for k in tot}
+        out["vt_close"] = np.zeros(0, bool)
+        return out
 
     split = hasattr(trainer, "backward_begin")
     feed = zip(plan, stream)
@@ -132,9 +160,14 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
         (b, lo, mine), batch = nxt
         if world > 1 and exchange is not None and hasattr(trainer, "set_global_batch"):
             global_normalisers(batch)
-        if split:
+        if batch is None:
+            if world <= 1:
+                raise RuntimeError("empty training batch")
+            out = sit_out()
+            nxt = next(feed, None)
+        elif split:
             # enqueue the step, then take delivery of the next batch (worker hand-over, unpickling) while the device works
-            trainer.backward_begin(batch.planes(), batch.targets, seed=reads_seed + epoch)
+            trainer.backward_begin(batch.planes(), batch.targets, seed=drop_seed)
             nxt = next(feed, None)
             if world > 1 and exchange is not None:
                 grad = trainer.grad_tensor()
@@ -149,12 +182,12 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
                 if world > 1:
                     average_gradients(trainer.grad_tensor(), world, all_reduce)
         else:
-            out = trainer.backward(batch.planes(), batch.targets, seed=reads_seed + epoch)
+            out = trainer.backward(batch.planes(), batch.targets, seed=drop_seed)
             nxt = next(feed, None)
             if world > 1:
                 average_gradients(trainer.grad_tensor(), world, all_reduce)
         trainer.apply()
-        flags = [(mine, out["vt_close"], batch.blacklist)]
+        flags = [(mine, out["vt_close"], batch.blacklist if batch is not None else np.zeros(0, bool))]
         if world > 1 and gather is not None:
             flags = gather(flags[0])
         for ids, close, black in flags:                                # trainer.py:263-267
@@ -179,9 +212,11 @@ def train_epoch(trainer, source: CandidateFile, sampler: EasyExampleSampler, hyp
 
 def evaluate(net, source: CandidateFile, hyper: TrainHyper, batch_size: int, write: Optional[Callable[[str], None]] = None,
              reads_seed: int = 0, max_batches: int = 0, indices: Optional[np.ndarray] = None,
-             prefetcher: Optional[BatchPrefetcher] = None) -> float:
+             prefetcher: Optional[BatchPrefetcher] = None, rank: int = 0, world: int = 1, reduce: bool = True):
     """Eval-mode pass over the test file (trainer.py:509-681): mean over batches of the loss mix; optionally the scored VCF
-    records.  ``net``: a ``DanNet`` (running BatchNorm statistics, no dropout)."""
+    records.  ``net``: a ``DanNet`` (running BatchNorm statistics, no dropout).  ``world > 1``: this rank takes the
+    ``rank``-th contiguous run of the batches (the runs concatenated in rank order are the single-process order);
+    ``reduce=False`` returns (sum of batch losses, batches) for the caller to sum over the ranks."""
     from .vcf import scored_record
     cfg = net.config
     idx_all = np.arange(len(source)) if indices is None else np.asarray(indices)
@@ -191,6 +226,8 @@ def evaluate(net, source: CandidateFile, hyper: TrainHyper, batch_size: int, wri
         if max_batches > 0 and b > max_batches:                       # trainer.py:513-515
             break
         plan.append(idx_all[lo:lo + batch_size])
+    if world > 1:
+        plan = plan[len(plan) * rank // world:len(plan) * (rank + 1) // world]
     kwargs = dict(max_reads=cfg.reads, seed=reads_seed, non_snp_train_weight=hyper.non_snp_train_weight, use_q=cfg.use_q,
                   use_strand=cfg.use_strand)
     if prefetcher is not None:
@@ -203,6 +240,8 @@ def evaluate(net, source: CandidateFile, hyper: TrainHyper, batch_size: int, wri
         n_batches += 1
         if write:
             write("".join(scored_record(r, bp, v) + "\n" for r, bp, v in zip(batch.sites.vcfrec, out["bp"], out["vt_prob"])))
+    if not reduce:
+        return total, n_batches
     return total / max(n_batches, 1)
 
 
@@ -215,9 +254,58 @@ def save_checkpoint(state: dict, is_best: bool, filename: str = "checkpoint.pth.
         torch.save(state, "{}_best{}".format(base, ext))
 
 
+def reference_parameter_order(cfg, fc_keys=("conv2hidden.1", "conv2hidden.4")):
+    """``[name for name, _ in Basic2DNet.named_parameters()]`` -- the index space of the reference's ``optim.Adam(model.
+    parameters())`` (main.py:116): the module's own two parameters first (model.py:429-431), then the children in the order
+    the constructor registers them (model.py:143,265-271,377,406-415).  Pinned against the reference's own list in
+    tests/golden/train_*.npz (tests/test_train_data.py)."""
+    names = ["bin_output_weights", "vt_output_weights", "embeddings.weight"]
+    n = cfg.layers
+    names += ["conv1D_layers.%d.%s" % (i, p) for i in range(n) for p in ("weight", "bias")]
+    names += ["bn1D_layers.%d.%s" % (i, p) for i in range(n) for p in ("weight", "bias")]
+    if cfg.bottleneck > 0:
+        names += ["conv1D_bottleneck_layers.%d.%s" % (i, p) for i in range(n) for p in ("weight", "bias")]
+        names += ["conv1D_compression_layers.%d.%s" % (i, p) for i in range(n) for p in ("weight", "bias")]
+    n_res = sum(1 for l in range(1, n + 1) if cfg.is_residual(l))                       # model.py:246-252
+    names += ["residual_conv_layers.%d.%s" % (i, p) for i in range(n_res) for p in ("weight", "bias")]
+    names += ["%s.%s" % (k, p) for k in fc_keys for p in ("weight", "bias")]
+    for head in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
+        names += [head + ".weight", head + ".bias"]
+    return names
+
+
+def optimizer_state(trainer) -> dict:
+    """``optimizer.state_dict()`` of the reference's Adam (main.py:116,198): ``state`` by parameter index (step, exp_avg,
+    exp_avg_sq) for every parameter a gradient reaches, and one ``param_groups`` entry -- what
+    ``torch.optim.Adam.load_state_dict`` accepts."""
+    import torch
+    hp = trainer.hyper
+    fc_keys = getattr(trainer, "_fc_keys", ("conv2hidden.1", "conv2hidden.4"))
+    names = reference_parameter_order(trainer.config, fc_keys)
+    step = int(trainer.query("step"))
+    state = {}
+    for i, name in enumerate(names):
+        ours = name
+        for j, k in enumerate(fc_keys):
+            if name.startswith(k + "."):
+                ours = "fc.%d.%s" % (j, name.rsplit(".", 1)[1])
+        if step == 0:
+            break
+        try:
+            m, v = trainer.tensor("m:" + ours), trainer.tensor("v:" + ours)
+        except (KeyError, RuntimeError):
+            continue                                              # no gradient reaches it (mixing scalars; BN affine with BN off)
+        state[i] = {"step": step, "exp_avg": torch.from_numpy(np.ascontiguousarray(m)),
+                    "exp_avg_sq": torch.from_numpy(np.ascontiguousarray(v))}
+    group = {"lr": float(hp.lr), "betas": (float(hp.beta1), float(hp.beta2)), "eps": float(hp.adam_eps), "weight_decay": 0,
+             "amsgrad": False, "params": list(range(len(names)))}
+    return {"state": state, "param_groups": [group], "param_names": names}
+
+
 def checkpoint_state(trainer, epoch: int, best_loss: float) -> dict:
-    """The dict the reference saves (main.py:194-199): DataParallel-prefixed state_dict + Adam state by parameter name."""
+    """The dict the reference saves (main.py:194-199): DataParallel-prefixed state_dict + the Adam state in torch's own
+    ``optimizer.state_dict()`` shape.  (As in the reference, ``--modelload`` restores the parameters only -- main.py:121-124
+    never calls ``optimizer.load_state_dict`` -- so a resumed run restarts Adam's moments from zero.)"""
     import torch
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in trainer.state_dict(prefix="module.").items()}
-    opt = {"step": trainer.query("step"), "lr": trainer.hyper.lr}
-    return {"epoch": epoch, "state_dict": sd, "best_loss": best_loss, "optimizer": opt}
+    return {"epoch": epoch, "state_dict": sd, "best_loss": best_loss, "optimizer": optimizer_state(trainer)}

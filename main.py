@@ -40,6 +40,32 @@ def child_devices(n: int):
     return have[:n]
 
 
+def wait_children(procs, poll_s: float = 0.2):
+    """Return codes of the child processes; as soon as ONE exits non-zero the others are terminated (a rank that died leaves
+    its siblings blocked in a collective until the backend's timeout -- and a parent waiting on them in rank order blocked
+    with them)."""
+    rcs = [None] * len(procs)
+    failed = False
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if not failed and any(rc not in (None, 0) for rc in rcs):
+            failed = True
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            deadline = time.time() + 20.0
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        if any(rc is None for rc in rcs):
+            time.sleep(poll_s)
+    return rcs
+
+
 def train_main(args, argv) -> int:
     """main.py:60-80,114-117,151-199: train for --epochs, evaluate on --test_file after every epoch, save checkpoints."""
     import numpy as np
@@ -81,7 +107,7 @@ def train_main(args, argv) -> int:
                        LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             env.pop("CUDA_VISIBLE_DEVICES", None)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-        rcs = [p.wait() for p in procs]
+        rcs = wait_children(procs)
         if any(rcs):
             raise SystemExit("training rank failed: %s" % rcs)
         return 0
@@ -91,7 +117,11 @@ def train_main(args, argv) -> int:
         import torch.distributed as dist
         backend = os.environ.get("DL4VC_DIST_BACKEND", "nccl")        # (tests rehearse two ranks on one GPU over gloo)
         torch.cuda.set_device(0)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # second line of defence behind the sharded evaluation below: a rank may legitimately wait long for another (check-
+        # point writes, uneven loader start-up), and the backend's default collective timeout (10 min on RCCL) would kill the run
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("DL4VC_DIST_TIMEOUT_S", "7200"))))
         all_reduce = dist.all_reduce
         from dl4vc_amd.train import GradientExchange
         exchange = GradientExchange(dist, world)                     # bucketed, overlapped with the backward pass
@@ -116,14 +146,20 @@ def train_main(args, argv) -> int:
     # loader workers (main.py:59-60: DataLoader(num_workers=args.num_data_workers)); 0 = assemble in this process
     with CandidateFile(args.train_file) as train_src, CandidateFile(args.test_file) as test_src, \
             BatchPrefetcher(args.train_file, args.num_data_workers) as train_loader, \
-            BatchPrefetcher(args.test_file, args.num_data_workers if rank == 0 else 0) as test_loader:
+            BatchPrefetcher(args.test_file, args.num_data_workers) as test_loader:
         holdout = None
         if args.train_holdout_chromosomes:
             holdout = np.zeros(len(train_src), bool)
             holdout[select_sites(args.train_file, args.train_holdout_chromosomes)] = True
         # every rank draws the same epoch order (same seed) and takes its DataParallel-style share of every batch
+        plain = args.close_examples_sample_rate >= 1.0                # main.py:72-77: then a plain shuffled loader, no sampler
+        if plain:
+            print("keeping all examples -- no close example down-sampling")
+            if holdout is not None and holdout.any():
+                print("WARNING: as in the reference (main.py:75-77), without the easy-example sampler the %d held-out sites are NOT "
+                      "skipped; use --close_examples_sample_rate < 1 to hold them out" % int(holdout.sum()))
         sampler = EasyExampleSampler(len(train_src), close_keep=min(1.0, args.close_examples_sample_rate), holdout=holdout,
-                                     rng=np.random.RandomState(args.seed))
+                                     rng=np.random.RandomState(args.seed), plain=plain)
         test_idx = select_sites(args.test_file, args.test_holdout_chromosomes) if args.test_holdout_chromosomes else None
         for epoch in range(1, args.epochs + 1):
             s = time.time()
@@ -139,23 +175,49 @@ def train_main(args, argv) -> int:
             if epoch <= args.epochs_skip_eval:
                 print("Skipping eval for epoch %d" % epoch)
                 continue
+            # evaluation is SHARDED over the ranks (the reference evaluates under the same DataParallel model, trainer.py:509-681):
+            # rank r scores a contiguous run of the test batches with the parameters every rank holds (rank 0's BatchNorm
+            # running statistics, broadcast -- DataParallel keeps replica 0's), the loss sums are reduced, the record text is
+            # concatenated in rank order = batch order.  No rank idles in a barrier while rank 0 walks a genome-scale file.
+            state = trainer.state_dict()
+            if dist is not None:
+                box = [state if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                state = box[0]
+            net = DanNet(cfg, device_id=0, max_batch=args.test_batch_size).load_state_dict(state)
+            out_path = None
+            if args.save_vcf_records:
+                assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"
+                out_path = scored_vcf_path(args.save_vcf_records_file, epoch)
+            part = (out_path + ".part%d" % rank) if (out_path and world > 1) else None
+            out = None
+            if out_path and rank == 0:
+                if args.sample_vcf:
+                    start_scored_vcf(args.sample_vcf, args.save_vcf_records_file, epoch)
+                else:
+                    open(out_path, "w").close()
+            if out_path:
+                out = open(part, "w") if part else open(out_path, "a")
+            loss_sum, n_eval = evaluate(net, test_src, hyper, args.test_batch_size, write=out.write if out else None,
+                                        reads_seed=args.reads_seed, max_batches=args.max_test_batches, indices=test_idx,
+                                        prefetcher=test_loader, rank=rank, world=world, reduce=False)
+            if out:
+                out.close()
+            net.close()
+            if dist is not None:
+                import torch
+                t = torch.tensor([loss_sum, float(n_eval)], dtype=torch.float64,
+                                 device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t)
+                loss_sum, n_eval = float(t[0]), int(t[1])
+            curloss = loss_sum / max(n_eval, 1)
             if rank == 0:
-                net = DanNet(cfg, device_id=0, max_batch=args.test_batch_size).load_state_dict(trainer.state_dict())
-                out = None
-                if args.save_vcf_records:
-                    assert args.save_vcf_records_file != "", "Need a valid filename for args.save_vcf_records_file to save records"
-                    if args.sample_vcf:
-                        out_path = start_scored_vcf(args.sample_vcf, args.save_vcf_records_file, epoch)
-                    else:
-                        out_path = scored_vcf_path(args.save_vcf_records_file, epoch)
-                        open(out_path, "w").close()
-                    out = open(out_path, "a")
-                curloss = evaluate(net, test_src, hyper, args.test_batch_size, write=out.write if out else None,
-                                   reads_seed=args.reads_seed, max_batches=args.max_test_batches, indices=test_idx,
-                                   prefetcher=test_loader)
-                if out:
-                    out.close()
-                net.close()
+                if part:
+                    with open(out_path, "a") as dst:
+                        for r in range(world):
+                            with open(out_path + ".part%d" % r) as src:
+                                dst.write(src.read())
+                            os.remove(out_path + ".part%d" % r)
                 print("\nTest set: Average loss: {:.6f}\n".format(curloss))
                 is_best = best_loss is None or curloss < best_loss
                 best_loss = curloss if best_loss is None else min(curloss, best_loss)
@@ -216,7 +278,7 @@ def main(argv=None) -> int:
             env.pop("CUDA_VISIBLE_DEVICES", None)             # (HIP honours both; the mask is carried in HIP_VISIBLE_DEVICES)
             cmd = [sys.executable, os.path.abspath(__file__)] + list(argv or sys.argv[1:]) + ["--shard", "%d/%d" % (g, args.gpus)]
             procs.append(subprocess.Popen(cmd, env=env))
-        rcs = [p.wait() for p in procs]
+        rcs = wait_children(procs)
         if any(rcs):
             for g in range(args.gpus):                        # no half-written parts left behind
                 try:

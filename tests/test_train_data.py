@@ -248,3 +248,162 @@ def test_batch_prefetcher_workers_yield_the_same_batches_in_order(tmp_path):
     with hdf5io.CandidateFile(path) as src:
         r = read_indices(src, np.array([5, 3, 4, 20]))
         assert [bytes(x["name"]) for x in r] == [bytes(recs[i]["name"]) for i in (5, 3, 4, 20)]
+
+
+# ------------------------------------------------------------------------------------------------
+# a short last batch leaves the last ranks without sites: nobody hangs, the replicas stay identical
+# ------------------------------------------------------------------------------------------------
+class ToyTrainer:
+    """DanTrainer's data-parallel surface on a five-parameter toy: the per-site gradient is a fixed function of the site's
+    planes, a rank's gradient is the sum over its sites divided by the full-batch normaliser it was handed
+    (set_global_batch), apply is plain SGD.  Then the average of the ranks' gradients is the full-batch mean gradient
+    whatever the split -- what include/dl4vc_dan_train.h promises for the real step."""
+
+    def __init__(self, cfg, hyper):
+        import torch
+        self.config, self.hyper = cfg, hyper
+        self.p = torch.zeros(5, dtype=torch.float64)
+        self.g = torch.zeros(5, dtype=torch.float64)
+        self.per_rank, self.steps, self.sat_out = None, 0, 0
+
+    def set_global_batch(self, sites_per_rank, vb, vr):
+        self.per_rank = float(sites_per_rank)
+
+    def _site_grad(self, planes):
+        import torch
+        reads, qual = planes[0].astype(np.float64), planes[1].astype(np.float64)
+        f = np.stack([reads.mean(axis=(1, 2)), qual.mean(axis=(1, 2)), reads.std(axis=(1, 2)), (reads[:, 0] % 3).mean(axis=1),
+                      np.ones(len(reads))], axis=1)
+        return torch.from_numpy(f.sum(axis=0))
+
+    def backward_begin(self, planes, targets, dropout_masks=None, seed=0):
+        n = len(planes[0])
+        self.g.copy_(self._site_grad(planes) / (self.per_rank if self.per_rank else n))
+        self._n = n
+
+    def wait_bucket(self, b):
+        pass
+
+    def backward_end(self):
+        return {**{k: 1.0 for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}, "vt_close": np.zeros(self._n, bool)}
+
+    def grad_tensor(self):
+        return self.g
+
+    def grad_buckets(self):
+        return [(2, 3), (0, 2)]
+
+    def apply(self):
+        self.p -= 0.1 * self.g
+        self.steps += 1
+        return float(self.g.norm())
+
+
+def _rank_short_tail(rank, world, port, path, q):
+    import torch.distributed as dist
+    from dl4vc_amd import hdf5io
+    from dl4vc_amd.config import DanConfig
+    from dl4vc_amd.trainer import train_epoch
+    from dl4vc_amd.train import GradientExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = DanConfig(reads=8, c_init=8, c_final=8, bottleneck=2, fc_sizes=(8, 4))
+    hp = TrainHyper(dropout=0.0)
+    tr = ToyTrainer(cfg, hp)
+    flags = []
+
+    def gather(item):
+        out = [None] * world
+        dist.all_gather_object(out, item)
+        return out
+
+    with hdf5io.CandidateFile(path) as src:
+        sm = EasyExampleSampler(len(src), close_keep=1.0, rng=np.random.RandomState(3))
+        orig = sm.update_close
+        sm.update_close = lambda ids, close: (flags.append(list(map(int, ids))), orig(ids, close))[1]
+        for epoch in (1, 2):
+            train_epoch(tr, src, sm, hp, batch_size=4, epoch=epoch, log=None, rank=rank, world=world,
+                        all_reduce=dist.all_reduce if world > 1 else None, gather=gather if world > 1 else None,
+                        exchange=GradientExchange(dist, world) if world > 1 else None)
+    q.put((rank, tr.p.tolist(), tr.steps, sorted(i for f in flags for i in f)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_short_last_batch_leaves_a_rank_without_sites_world2_gloo(tmp_path):
+    """9 sites in batches of 4 over 2 ranks: the last batch holds ONE site, so rank 1 has nothing in it (DataParallel's
+    torch.chunk split, main.py:117: it then runs one replica).  Both ranks finish both epochs (no collective left waiting),
+    take the same number of optimiser steps, end with bit-identical parameters, and those equal the single-process run --
+    the averaged gradient is the full-batch gradient for the 2+2, 2+2 and 1+0 splits alike."""
+    import torch.multiprocessing as mp
+    from dl4vc_amd import hdf5io
+    path = str(tmp_path / "train.hdf")
+    hdf5io.write_candidates(path, _records(9, 8, 77))
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 33700 + (os.getpid() % 2000) + world
+        ps = [ctx.Process(target=_rank_short_tail, args=(r, world, port, path, q)) for r in range(world)]
+        for p in ps:
+            p.start()
+        got = [q.get(timeout=180) for _ in ps]
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        res[world] = {r: (p_, s, f) for r, p_, s, f in got}
+    p1, s1, f1 = res[1][0]
+    assert s1 == 6                                                   # 3 batches x 2 epochs
+    for r in (0, 1):
+        p2, s2, f2 = res[2][r]
+        assert s2 == 6 and f2 == f1 == sorted(list(range(9)) * 2)    # every site's flags reached every rank's sampler, once per epoch
+        assert np.allclose(p2, p1, rtol=1e-12, atol=1e-12), (r, p2, p1)
+    assert res[2][0][0] == res[2][1][0]                              # replicas identical bit for bit
+
+
+def test_reference_parameter_order_and_optimizer_state_shape():
+    """The index space of the reference's Adam state (optim.Adam(model.parameters()), main.py:116,198) restated from the
+    configuration equals the reference's own named_parameters() order -- the order of the parameter keys of the state dict
+    its training loop left in tests/golden/train_*.npz -- for all six structures; the checkpoint's 'optimizer' entry loads
+    into a torch Adam over tensors of those shapes."""
+    import torch
+    from golden_util import load_train_case, train_cases
+    from dl4vc_amd.config import DanConfig
+    from dl4vc_amd.trainer import reference_parameter_order, optimizer_state
+    buffers = ("pe", "running_mean", "running_var", "num_batches_tracked")
+    for case in train_cases():
+        spec, hyper, w, steps, final, adam, close = load_train_case(case)
+        keys = DanConfig.__dataclass_fields__.keys()
+        cfg = DanConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in keys})
+        want = [k for k in final if not k.endswith(buffers)]
+        fc = sorted({k.rsplit(".", 1)[0] for k in want if k.startswith("conv2hidden.")}, key=lambda k: int(k.split(".")[1]))
+        assert reference_parameter_order(cfg, tuple(fc)) == want, case
+
+    class Stub:                                                      # DanTrainer's read-only surface, moments = the fixture's
+        def __init__(self, cfg, hp, adam, fc):
+            self.config, self.hyper, self._fc_keys, self.adam = cfg, hp, fc, adam
+
+        def query(self, what):
+            return 2
+
+        def tensor(self, name):
+            kind, base = name.split(":", 1)
+            if base.startswith("fc."):
+                base = "%s.%s" % (self._fc_keys[int(base.split(".")[1])], base.split(".")[2])
+            return self.adam["adam_%s:%s" % (kind, base)]            # KeyError where no gradient reaches
+
+    spec, hyper, w, steps, final, adam, close = load_train_case("train_small")
+    cfg = DanConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items() if k in DanConfig.__dataclass_fields__})
+    hp = TrainHyper(**{k: v for k, v in hyper.items() if k in TrainHyper.__dataclass_fields__})
+    fc = tuple(sorted({k.rsplit(".", 1)[0] for k in final if k.startswith("conv2hidden.")}, key=lambda k: int(k.split(".")[1])))
+    od = optimizer_state(Stub(cfg, hp, adam, fc))
+    names = od.pop("param_names")
+    params = [torch.nn.Parameter(torch.from_numpy(np.array(final[k], dtype=np.float32))) for k in names]
+    opt = torch.optim.Adam(params, lr=1.0)
+    opt.load_state_dict(od)                                          # what a tool written against the reference's checkpoints does
+    st = opt.state_dict()["state"]
+    i = names.index("conv1D_layers.2.weight")
+    assert np.array_equal(st[i]["exp_avg"].numpy(), adam["adam_m:conv1D_layers.2.weight"]) and float(st[i]["step"]) == 2
+    assert names.index("bin_output_weights") not in st and opt.param_groups[0]["lr"] == hp.lr
