@@ -152,39 +152,78 @@ def encode(spec: OracleSpec, sd, reads, qual, strand, ref, ref_mask, var_mask, d
     return x.permute(0, 3, 1, 2).contiguous()         # (B,Cin,R,L)  == transpose(1,3) of (B,L,R,C)
 
 
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> nearest bf16 (ties to even, what ``v_cvt_pk_bf16_f32`` does) -> fp32."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+BF16_MODES = (None, "operands", "storage")
+
+
+@torch.no_grad()
+def conv_layer(spec: OracleSpec, sd, l: int, x, pool=None, bf16: Optional[str] = None):
+    """One pass of the layer loop, model.py:728-778, for the 1-based layer ``l``: input ``x`` (B,C,R,L) = the previous layer's
+    output (or the encoded input), ``pool`` = the read-mean to add first when layer l-1 is a pool layer.
+    Returns (y_l, h_l or None): the layer's output and its ReLU'd bottleneck (B,H,R,L) -- model.py:774.
+
+    ``bf16`` (BASELINE config 5; the reference has no such mode -- it is what "run the GEMMs on the bf16 matrix cores" means):
+      "operands": the two operands of every conv / residual 1x1 / bottleneck GEMM are rounded to bf16, sums are fp32,
+                  everything else (bias, ReLU, BatchNorm, residual add, pooling, compression, FC) is the fp32 arithmetic
+                  above.  Pinned against the live reference run with bf16-rounded weights and forward-pre-hooks that round
+                  the inputs of those modules (tests/test_vs_live_reference.py).
+      "storage":  "operands" plus the roundings of the HIP kernel's bf16 activation STORAGE (dan_kernels_bf16p.hip): a
+                  layer's output y_l, the BatchNorm output feeding the residual 1x1, the pool-added input of the next
+                  segment and the bottleneck h_l are held as bf16 -- so the residual branch adds the bf16 value of x and the
+                  read-mean averages bf16 values.  Each is one more rounding of a value "operands" rounds anyway at its next
+                  use as an operand; the GPU parity test holds the kernel to THIS mode layer by layer."""
+    assert bf16 in BF16_MODES
+    rb = bf16_round if bf16 else (lambda t: t)
+    st = bf16_round if bf16 == "storage" else (lambda t: t)
+    _, _, dil = spec.layer_dims(l)
+    residual = x                                                 # model.py:732 (before the pool add)
+    if pool is not None:
+        x = st(x + pool)                                         # model.py:742
+    W = sd["conv1D_layers.%d.weight" % (l - 1)]
+    b = sd["conv1D_layers.%d.bias" % (l - 1)]
+    x = F.relu(F.conv2d(rb(x), rb(W), b, padding=(0, dil), dilation=(1, dil)))     # model.py:749
+    if spec.use_bn:                                              # eval-mode BN AFTER the ReLU, model.py:750-751
+        p = "bn1D_layers.%d." % (l - 1)
+        x = F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"],
+                         sd[p + "weight"], sd[p + "bias"], training=False, eps=BN_EPS)
+    x = st(x)
+    if spec.is_residual(l):
+        i = l - spec.residual_start                              # model.py:760
+        x = F.conv2d(rb(x), rb(sd["residual_conv_layers.%d.weight" % i]), sd["residual_conv_layers.%d.bias" % i])
+        x = st(x + residual)                                     # model.py:761
+    h = None
+    if spec.bottleneck > 0:
+        h = st(F.relu(F.conv2d(rb(x), rb(sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)]),
+                               sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)])))       # model.py:774
+    return x, h
+
+
 @torch.no_grad()
 def dan_forward_oracle(state_dict, cfg, reads, qual, strand, ref, ref_mask, var_mask,
-                       taps: bool = False, dtype=torch.float32) -> Dict[str, np.ndarray]:
+                       taps: bool = False, dtype=torch.float32, bf16: Optional[str] = None) -> Dict[str, np.ndarray]:
     """Full forward.  Returns numpy arrays:
     bin_logits (B,2) vt_logits (B,3) af (B,1) cov (B,1) vb (B,10) vr (B,10)  -- model.py:919-958
     vt_prob (B,3) bp (B,)                                                  -- trainer.py:609-623
     with ``taps``: conv{l} (B,C,R,L), hw{l} (B,H*R), pool{l}, feature (B,F), hidden (B,fc[-1]).
+    ``bf16``: None (the reference's fp32 arithmetic) | "operands" | "storage" -- see ``conv_layer``.
     """
     spec = spec_from(cfg)
     sd = _strip(state_dict, dtype)
     out: Dict[str, np.ndarray] = {}
     x = encode(spec, sd, reads, qual, strand, ref, ref_mask, var_mask, dtype)
+    if bf16 == "storage":
+        x = bf16_round(x)
     B, _, R, L = x.shape
     if taps:
         out["encoded"] = x.numpy().copy()
     pool = None
     hws = []
     for l in range(1, spec.layers + 1):
-        _, _, dil = spec.layer_dims(l)
-        residual = x                                             # model.py:732 (before the pool add)
-        if (l - 1) in spec.pool_layers:
-            x = x + pool                                         # model.py:742
-        W = sd["conv1D_layers.%d.weight" % (l - 1)]
-        b = sd["conv1D_layers.%d.bias" % (l - 1)]
-        x = F.relu(F.conv2d(x, W, b, padding=(0, dil), dilation=(1, dil)))     # model.py:749
-        if spec.use_bn:                                          # eval-mode BN AFTER the ReLU, model.py:750-751
-            p = "bn1D_layers.%d." % (l - 1)
-            x = F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"],
-                             sd[p + "weight"], sd[p + "bias"], training=False, eps=BN_EPS)
-        if spec.is_residual(l):
-            i = l - spec.residual_start                          # model.py:760
-            x = F.conv2d(x, sd["residual_conv_layers.%d.weight" % i], sd["residual_conv_layers.%d.bias" % i])
-            x = x + residual                                     # model.py:761
+        x, h = conv_layer(spec, sd, l, x, pool if (l - 1) in spec.pool_layers else None, bf16)
         if taps:
             out["conv%d" % l] = x.numpy().copy()
         if l in spec.pool_layers:
@@ -192,8 +231,8 @@ def dan_forward_oracle(state_dict, cfg, reads, qual, strand, ref, ref_mask, var_
             if taps:
                 out["pool%d" % l] = pool.numpy().copy()
         if spec.bottleneck > 0:
-            h = F.relu(F.conv2d(x, sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)],
-                                sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)]))       # model.py:774
+            if taps:
+                out["h%d" % l] = h.numpy().copy()
             hw = F.conv2d(h, sd["conv1D_compression_layers.%d.weight" % (l - 1)],
                           sd["conv1D_compression_layers.%d.bias" % (l - 1)])            # (B,H,R,1) model.py:776
             hw = hw.squeeze(3).reshape(B, -1)                    # channel-major, read-minor  model.py:777

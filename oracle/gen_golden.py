@@ -101,9 +101,19 @@ def build_reference_model(m, spec: OracleSpec, dropout=0.1):
     return net.eval()
 
 
-def run_reference(m, spec: OracleSpec, sd_np, batch: synth.SiteBatch, dropout=0.1, taps=True):
+GEMM_MODULES = ("conv1D_layers.", "residual_conv_layers.", "conv1D_bottleneck_layers.")
+
+
+def run_reference(m, spec: OracleSpec, sd_np, batch: synth.SiteBatch, dropout=0.1, taps=True, bf16_operands=False):
+    """``bf16_operands``: the reference run "on bf16 matrix cores" -- the weights of every conv / residual 1x1 / bottleneck
+    module rounded to bf16 and a forward-pre-hook on each of those modules that rounds its input to bf16; biases, sums and
+    everything else stay the reference's own fp32 code.  Pins the oracle's bf16 = "operands" mode."""
     net = build_reference_model(m, spec, dropout)
     sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    if bf16_operands:
+        for k in list(sd_t):
+            if k.startswith(GEMM_MODULES) and k.endswith(".weight"):
+                sd_t[k] = sd_t[k].to(torch.bfloat16).to(torch.float32)
     for k, v in net.state_dict().items():               # BN bookkeeping the reference carries, not a weight
         if k.endswith("num_batches_tracked"):
             sd_t[k] = v
@@ -123,6 +133,13 @@ def run_reference(m, spec: OracleSpec, sd_np, batch: synth.SiteBatch, dropout=0.
             lambda _m, inp: cap.__setitem__("feature", inp[0].detach().numpy().copy())))
         hooks.append(net.conv2hidden.register_forward_hook(
             lambda _m, inp, out: cap.__setitem__("hidden", out.detach().numpy().copy())))
+
+    if bf16_operands:                                   # (after the tap hooks: those record what the module was GIVEN)
+        lists = [net.conv1D_layers] + ([net.residual_conv_layers] if len(net.residual_conv_layers) else []) + \
+                ([net.conv1D_bottleneck_layers] if spec.bottleneck > 0 else [])
+        for ml in lists:
+            for mod in ml:
+                hooks.append(mod.register_forward_pre_hook(lambda _m, inp: (inp[0].to(torch.bfloat16).to(torch.float32),)))
 
     def pm(a):      # our [B][R][L] -> the reference's (B, L, R) int64  (dataset.py:521, trainer.py:520-528)
         return torch.from_numpy(np.ascontiguousarray(np.transpose(a, (0, 2, 1)))).long()

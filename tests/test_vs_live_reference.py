@@ -49,6 +49,42 @@ def test_random_structural_configs_oracle_equals_reference(ref):
             np.testing.assert_allclose(got[k], v, atol=2e-5 * max(1.0, float(np.abs(v).max())), err_msg="%s %s" % (spec, k))
 
 
+def test_bf16_operand_mode_of_the_oracle_equals_the_reference_run_with_bf16_rounded_gemm_operands(ref):
+    """BASELINE config 5 computes in bf16.  The reference has no such mode; what it means is pinned here: the reference's OWN
+    forward with the weights of every conv / residual 1x1 / bottleneck module rounded to bf16 and the inputs of those modules
+    rounded to bf16 by forward-pre-hooks (fp32 sums, everything else untouched) equals the oracle's bf16 = "operands" mode --
+    on random structures and on the production structure at 301 columns.  The "storage" mode (the HIP kernel's bf16 activation
+    storage on top) stays within the bf16 bound of it."""
+    from oracle.dan_oracle import OracleSpec, random_state_dict, dan_forward_oracle
+    from dl4vc_amd import synth
+    G, m, d, u = ref
+    rng = random.Random(11)
+    specs = [OracleSpec(reads=6, length=301, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8))]
+    for trial in range(4):
+        layers = rng.choice([3, 5, 7])
+        pools = tuple(sorted(rng.sample(range(1, layers), rng.choice([0, 1]))))
+        specs.append(OracleSpec(reads=rng.choice([3, 5]), c_init=rng.choice([8, 12]), c_final=rng.choice([8, 12]), layers=layers,
+                                pool_layers=pools, residual_start=rng.choice([0, 2, 3]), dil_mid=rng.choice([1, 2]),
+                                dil_final=2, use_bn=rng.random() < 0.7, bottleneck=rng.choice([0, 4]), fc_sizes=(8, 4)))
+    for i, spec in enumerate(specs):
+        if spec.residual_start > spec.layers:
+            continue
+        sd = random_state_dict(spec, seed=700 + i)
+        batch = synth.make_sites(3, reads=spec.reads, length=spec.length, seed=800 + i)
+        want = G.run_reference(m, spec, sd, batch, taps=True, bf16_operands=True)
+        got = dan_forward_oracle(sd, spec, *batch.arrays(), taps=True, bf16="operands")
+        plain = dan_forward_oracle(sd, spec, *batch.arrays(), taps=True)
+        stor = dan_forward_oracle(sd, spec, *batch.arrays(), taps=True, bf16="storage")
+        moved = 0.0
+        for k, v in want.items():
+            sc = max(1.0, float(np.abs(v).max()))
+            # the same arithmetic on the same torch kernels: the fp32-vs-fp32 bar (observed: conv taps bit-identical)
+            np.testing.assert_allclose(got[k], v, atol=2e-5 * sc, err_msg="%s %s" % (spec, k))
+            moved = max(moved, float(np.abs(plain[k] - v).max()) / sc)
+            assert float(np.abs(stor[k] - v).max()) <= 4e-2 * sc, (spec, k)
+        assert moved > 1e-4, "the hooks rounded nothing: %g" % moved      # the mode IS different from fp32
+
+
 def test_random_alleles_equal_reference(ref):
     from dl4vc_amd import alleles
     G, m, d, u = ref
