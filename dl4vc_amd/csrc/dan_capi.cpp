@@ -52,6 +52,9 @@ struct dan_handle {
     std::vector<void*> allocs;
     float* d_wl = nullptr;                   // [layers][LAYER_STRIDE] weight blocks (fp32 path)
     char* d_wl16 = nullptr;                  // [layers][W16_LAYER_BYTES] bf16 hi/lo weight blocks (precision 1, 2)
+    char* d_wlp = nullptr;                   // [layers][WP_LAYER_BYTES] 32x32x16 fragments of the ping-pong bf16 kernel (precision 2)
+    float* d_wc16 = nullptr;                 // compression weights in the channel order of a 16-byte bf16 load of h
+    bool use_p = false;                      // precision 2 on dan_kernels_bf16p.hip: y and h cross HBM as bf16
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
@@ -176,7 +179,27 @@ uint16_t bf16_bits(float x) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+// MFMA 32x32x16 bf16 A-fragment order of the ping-pong kernel (dan_kernels.h): fragment ((t * 8 + ks) * nq + q), lane, j:
+//   row m = lane & 31 -> output channel 32 q + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3),  k = 16 ks + 8 (lane >> 5) + j
+template <typename F>
+void pack_fragp(uint16_t* dst, int taps, int ksteps, int nq, F W);
+
 float bf16_float(uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; }
+
+template <typename F>
+void pack_fragp(uint16_t* dst, int taps, int ksteps, int nq, F W) {
+    for (int t = 0; t < taps; ++t)
+        for (int ks = 0; ks < ksteps; ++ks)
+            for (int q = 0; q < nq; ++q) {
+                uint16_t* f = dst + ((size_t)(t * P_KSC + ks) * nq + q) * (WP_FRAG / 2);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = lane & 31;
+                        const int o = 32 * q + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+                        f[lane * 8 + j] = bf16_bits(W(o, 16 * ks + 8 * (lane >> 5) + j, t));
+                    }
+            }
+}
 
 // MFMA 16x16x32 bf16 A-fragment order, hi plane then lo plane (lo = bf16(w - hi)):
 //   plane[((tap*kg + g)*tiles + n)*64 + lane][j] = W[o = 16n + (lane&15)][c = 32g + 8(lane>>4) + j][tap]
@@ -324,6 +347,20 @@ int dan_finalize(dan_t* h) {
     // ---- conv stack: one fixed-stride weight block per layer (dan_kernels.h)
     std::vector<float> wl((size_t)c.layers * LAYER_STRIDE, 0.f);
     std::vector<char> wl16(c.precision ? (size_t)c.layers * W16_LAYER_BYTES : 0, 0);
+    // precision 2 runs on the ping-pong kernel (bf16 y / h in HBM) unless the structure needs the older forms or
+    // DAN_BF16_FORM = 4 | 8 asks for them (A/B runs, the form-vs-form tests)
+    {
+        const char* form_env = getenv("DAN_BF16_FORM");
+        bool ok = c.precision == 2 && !(form_env && (form_env[0] == '4' || form_env[0] == '8'));
+        unsigned rm = 0;
+        for (int l1 = 1; l1 <= c.layers; ++l1) if (is_residual(c, l1)) rm |= 1u << (l1 - 1);
+        for (int sg = 0; ok && sg < h->n_segments; ++sg) ok = segmentp_supports(L, h->seg_begin[sg], rm, sg > 0);
+        h->use_p = ok;
+    }
+    std::vector<char> wlp(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
+    std::vector<float> wc16_all;
+    const size_t wc16_layer = (size_t)L * 2 * 64 * 8;        // [pos][n 2][lane 64][8]
+    if (h->use_p && H > 0) wc16_all.resize((size_t)c.layers * wc16_layer);
     std::vector<float> wc_all, bc_all((size_t)c.layers * HPAD, 0.f);
     const size_t wc_layer = (size_t)L * 2 * 2 * 64 * 4;      // [g = 2L][tile 2][lane 64][4]
     if (H > 0) wc_all.resize((size_t)c.layers * wc_layer);
@@ -366,6 +403,8 @@ int dan_finalize(dan_t* h) {
             auto Wf16 = [&](int o, int cc, int t) -> float { return Wf(o, cc, t); };   // channels beyond kg*16 read as 0
             pack_frag16((uint16_t*)(blk16 + W16_CONV_OFF), W16_CONV_FRAGS, 3, l == 0 ? KG16_0 : KG16_C, KGC, Wf16);
         }
+        char* blkp = h->use_p ? wlp.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
+        if (blkp) pack_fragp((uint16_t*)(blkp + WP_CONV_OFF), 3, l == 0 ? P_KS0 : P_KSC, 4, Wf);
         float* cst = blk + CST_OFF;
         for (int o = 0; o < cout; ++o) { cst[CST_BIAS + o] = b->data[o]; cst[CST_SCALE + o] = 1.f; }
         if (c.use_bn) {                                      // eval-mode BN after the ReLU, eps 1e-5 (model.py:750-751)
@@ -388,6 +427,7 @@ int dan_finalize(dan_t* h) {
             std::vector<float> pr = pack_frag(1, KGC, KGC, Wr);
             std::copy(pr.begin(), pr.end(), blk + WRES_OFF);
             if (blk16) pack_frag16((uint16_t*)(blk16 + W16_RES_OFF), W16_RES_FRAGS, 1, KG16_C, KGC, Wr);
+            if (blkp) pack_fragp((uint16_t*)(blkp + WP_RES_OFF), 1, P_KSC, 4, Wr);
             for (int o = 0; o < cout; ++o) cst[CST_BRES + o] = br->data[o];
             h->res_mask |= 1u << l;
         }
@@ -399,6 +439,7 @@ int dan_finalize(dan_t* h) {
             std::vector<float> pb = pack_frag(1, KGC, 2, Wb);
             std::copy(pb.begin(), pb.end(), blk + WBOT_OFF);
             if (blk16) pack_frag16((uint16_t*)(blk16 + W16_BOT_OFF), W16_BOT_FRAGS, 1, KG16_C, 2, Wb);
+            if (blkp) pack_fragp((uint16_t*)(blkp + WP_BOT_OFF), 1, P_KSC, 1, Wb);
             for (int o = 0; o < H; ++o) cst[CST_BBOT + o] = bb->data[o];
             const std::string z = "conv1D_compression_layers." + std::to_string(l);
             const Tensor* wcm = need(h, z + ".weight", {H, H, 1, L}, &rc); if (!wcm) return rc;
@@ -414,7 +455,25 @@ int dan_finalize(dan_t* h) {
                             dst[i++] = (o < H && cc < H) ? wcm->data[((size_t)o * H + cc) * L + pp] : 0.f;
                         }
             for (int o = 0; o < H; ++o) bc_all[(size_t)l * HPAD + o] = bcm->data[o];
+            if (h->use_p) {
+                float* d16 = wc16_all.data() + (size_t)l * wc16_layer;
+                size_t k = 0;
+                for (int pp = 0; pp < L; ++pp)
+                    for (int n = 0; n < 2; ++n)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int s8 = 0; s8 < 8; ++s8) {
+                                const int o = 16 * n + (lane & 15), cc = 8 * (lane >> 4) + s8;
+                                d16[k++] = (o < H && cc < H) ? wcm->data[((size_t)o * H + cc) * L + pp] : 0.f;
+                            }
+            }
         }
+    }
+    if (h->use_p) {
+        for (int l = 0; l < c.layers; ++l)
+            memcpy(wlp.data() + (size_t)l * WP_LAYER_BYTES + WP_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
+                   CST_FLOATS * sizeof(float));
+        if ((rc = dev_upload(h, &h->d_wlp, wlp))) return rc;
+        if (H > 0 && (rc = dev_upload(h, &h->d_wc16, wc16_all))) return rc;
     }
     if (c.precision) {                                       // constants are shared: copy each layer's fp32 block tail
         for (int l = 0; l < c.layers; ++l)
@@ -545,6 +604,15 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (c.precision == 0) {
                     launch_segment(a, ns, h->n_cus, s);
+                } else if (h->use_p) {
+                    SegmentPArgs b{};
+                    b.wl = h->d_wlp; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
+                    b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
+                    b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
+                    b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
+                    b.y = (uint16_t*)h->d_y; b.pool = a.pool; b.h = (uint16_t*)h->d_h; b.h_layer_stride = a.h_layer_stride;
+                    b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
+                    launch_segmentp(b, ns, h->n_cus, s);
                 } else {
                     Segment16Args b{};
                     b.wl = h->d_wl16; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
@@ -557,7 +625,8 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-                    launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                    if (h->use_p) launch_read_mean16((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                    else launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
                     rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
                     HIPCHK(h, hipGetLastError());            // a refused launch must not let garbage flow on to the FC
                 }
@@ -565,13 +634,18 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
             float* feat = h->d_feat + (size_t)c0 * h->F_stride;
             EventPair ev{};
             int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-            launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
+            if (h->use_p) launch_final_pool16((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
+            else launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
             HIPCHK(h, hipGetLastError());
             if (H > 0) {
                 rc = prof_begin(h, "highway", s, &ev); if (rc) return rc;
-                launch_highway(h->d_h, h_layer_stride, h->d_wc, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat, h->F_stride,
-                               2 * c.c_final * L, ns, R, L, H, c.layers, h->d_rowsrc, s);
+                if (h->use_p)
+                    launch_highway16((const uint16_t*)h->d_h, h_layer_stride, h->d_wc16, (long long)L * 2 * 64 * 8, h->d_bc, feat,
+                                     h->F_stride, 2 * c.c_final * L, ns, R, L, H, c.layers, h->d_rowsrc, s);
+                else
+                    launch_highway(h->d_h, h_layer_stride, h->d_wc, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat, h->F_stride,
+                                   2 * c.c_final * L, ns, R, L, H, c.layers, h->d_rowsrc, s);
                 rc = prof_end(h, "highway", s, &ev); if (rc) return rc;
             }
             h->last_chunk_sites = ns;
@@ -738,6 +812,7 @@ int64_t dan_query(const dan_t* h, const char* what) {
     if (w == "cpad") return CPAD;
     if (w == "tap_sites") return h->last_chunk_sites;
     if (w == "segments") return h->n_segments;
+    if (w == "bf16_pingpong") return h->use_p ? 1 : 0;
     if (w == "hidden0_stride") return h->n0_stride;
     return fail(h, DAN_ERR_INVALID_ARG, "dan_query: unknown key '%s'", what);
 }
@@ -753,6 +828,27 @@ int64_t dan_read_buffer(dan_t* h, const char* name, float* dst, int64_t capacity
     else if (w == "feature") { src = h->d_feat; n = h->last_batch * h->F_stride; }
     else if (w == "hidden0") { src = h->d_hid0; n = h->last_batch * h->n0_stride; }
     else if (w == "hidden1") { src = h->d_hid1; n = h->last_batch * c.fc_sizes[1]; }
+    else if (w == "pool") { src = h->d_pool; n = (int64_t)h->last_chunk_sites * c.length * CPAD; }
+    else if (w == "h") {
+        // bottleneck outputs of the last chunk, [layer][site][read][L][HPAD] (layer stride = the chunk's capacity); bf16 on the
+        // ping-pong kernel: widened here
+        if (!h->d_h) return fail(h, DAN_ERR_STATE, "the network has no highway bottleneck");
+        const int64_t per_layer = (int64_t)h->last_chunk_sites * c.reads * c.length * HPAD;
+        const int64_t stride = (int64_t)h->chunk * c.reads * c.length * HPAD;
+        n = std::min<int64_t>(per_layer * c.layers, capacity) / per_layer * per_layer;
+        HIPCHK(h, hipSetDevice(c.device_id));
+        HIPCHK(h, hipDeviceSynchronize());
+        for (int64_t l = 0; l * per_layer < n; ++l) {
+            if (h->use_p) {
+                std::vector<uint16_t> tmp((size_t)per_layer);
+                HIPCHK(h, hipMemcpy(tmp.data(), (const uint16_t*)h->d_h + l * stride, (size_t)per_layer * 2, hipMemcpyDeviceToHost));
+                for (int64_t i = 0; i < per_layer; ++i) dst[l * per_layer + i] = bf16_float(tmp[(size_t)i]);
+            } else {
+                HIPCHK(h, hipMemcpy(dst + l * per_layer, h->d_h + l * stride, (size_t)per_layer * sizeof(float), hipMemcpyDeviceToHost));
+            }
+        }
+        return n;
+    }
     else return fail(h, DAN_ERR_INVALID_ARG, "dan_read_buffer: unknown buffer '%s'", name);
     n = std::min(n, capacity);
     HIPCHK(h, hipSetDevice(c.device_id));

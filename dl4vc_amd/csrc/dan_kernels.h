@@ -113,6 +113,63 @@ struct Segment16Args {
 void launch_segment16(const Segment16Args& a, int n_sites, int precision, int max_wgs, hipStream_t s);
 // plain bf16, one workgroup per row, two workgroups resident per CU (dan_kernels_bf16w.hip)
 void launch_segment16w(const Segment16Args& a, int n_sites, hipStream_t s);
+// ---- bf16 "ping-pong" kernel (dan_kernels_bf16p.hip): plain bf16, v_mfma_f32_32x32x16_bf16, two XOR-swizzled LDS images
+// (layer input / layer output), bf16 activations in HBM (y, h), persistent workgroups.  BASELINE config 5 (128 x 301).
+constexpr int P_HALO = 4;                 // zero rows either side of the window (dilation <= 4)
+constexpr int P_ROW_BYTES = 256;          // one position = 128 bf16 channels, 16 chunks of 16 B, chunk c of row r stored at c ^ (r & 15)
+constexpr int P_LMAX = 304;               // window columns the two images hold: 2 x (4 + 304 + 4) rows x 256 B = 159 744 B of the 160 KiB
+constexpr int P_ROWS = P_LMAX + 2 * P_HALO;
+constexpr int P_IMG_BYTES = P_ROWS * P_ROW_BYTES;
+constexpr int P_LDS_BYTES = 163840;
+constexpr int P_KS0 = CIN0 / 16;          // 16-channel k-steps of layer 1 (48 encoded channels)
+constexpr int P_KSC = CPAD / 16;          // 8
+// per-layer weight block (bytes): MFMA 32x32x16 A fragments, 1 KiB each ([lane 64][8 bf16]); the 32 rows of a fragment are the
+// output channels of one channel quarter q in the order row m -> channel 32 q + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3), so
+// that a lane's 16 accumulator registers are 16 CONSECUTIVE channels (32 q + 16 (lane >> 5) + reg)
+//   [WP_CONV_OFF) conv      [tap 3][kstep 8][q 4] fragments   (layer 1 uses ksteps 0..2)
+//   [WP_RES_OFF)  residual  [kstep 8][q 4]
+//   [WP_BOT_OFF)  bottleneck [kstep 8]                         (32 outputs: one row tile)
+//   [WP_CST_OFF)  the fp32 constants of the layer (bias, scale, shift, bres, bbot), as in the other families
+constexpr int WP_FRAG = 1024;
+constexpr int WP_CONV_OFF = 0;
+constexpr int WP_RES_OFF = WP_CONV_OFF + 3 * P_KSC * 4 * WP_FRAG;     // 98304
+constexpr int WP_BOT_OFF = WP_RES_OFF + P_KSC * 4 * WP_FRAG;          // 131072
+constexpr int WP_CST_OFF = WP_BOT_OFF + P_KSC * WP_FRAG;              // 139264
+constexpr int WP_LAYER_BYTES = WP_CST_OFF + (CST_FLOATS + 32) * 4;
+
+struct SegmentPArgs {
+    const char* wl;              // [layers][WP_LAYER_BYTES]
+    int l_begin, l_end, n_layers, dil_mid, dil_final;
+    unsigned res_mask;
+    int has_hw;
+    int R, L;
+    const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
+    const float* emb;
+    const float* pe;
+    uint16_t* y;                 // bf16 [site][read][L][CPAD]   in/out
+    const float* pool;           // fp32 [site][L][CPAD] or nullptr
+    uint16_t* h;                 // bf16 [layer][site][read][L][HPAD] or nullptr
+    long long h_layer_stride;    // elements between layers of h
+    float* tap;                  // fp32 [site][read][L][CPAD] or nullptr
+    int tap_layer;
+    int n_rows;                  // filled by the launcher
+    int slice_rows;              // filled by the launcher: rows per XCD slice (whole sites)
+    const int* work;
+    const int* work_count;
+};
+// true if the structure can run on this kernel (else the eight-wave / two-workgroup kernels take it)
+bool segmentp_supports(int L, int l_begin, unsigned res_mask, bool has_pool);
+void launch_segmentp(const SegmentPArgs& a, int n_sites, int n_cus, hipStream_t s);
+// bf16-input forms of the three reductions
+void launch_read_mean16(const uint16_t* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s);
+void launch_final_pool16(const uint16_t* y, float* feat, long long feat_stride, int n_sites, int R, int L, int C,
+                         const int* row_src, hipStream_t s);
+// wc16: compression weights packed [layer][pos][n 2][lane 64][8]  (B fragments of v_mfma_f32_16x16x4_f32 for the channel order
+// a 16-byte bf16 load of h delivers: lane (o = lane & 15, kk = lane >> 4), element s -> Wc[16 n + o][8 kk + s][pos])
+void launch_highway16(const uint16_t* h, long long h_layer_stride, const float* wc16, long long wc_layer_stride,
+                      const float* bc, float* feat, long long feat_stride, int feat_off, int n_sites, int R, int L,
+                      int H, int layers, const int* row_src, hipStream_t s);
+
 // Empty-row map: a pileup row whose reads / qual / strand bytes are all zero (padding below the site's coverage) encodes to
 // the same activations as every other such row of its site, through every layer.  row_src[site*R + r] = site*R + (first
 // empty row of the site) for an empty row, site*R + r otherwise; the segment kernels walk only the rows that are their own
