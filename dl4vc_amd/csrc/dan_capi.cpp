@@ -54,6 +54,7 @@ struct dan_handle {
     char* d_wl16 = nullptr;                  // [layers][W16_LAYER_BYTES] bf16 hi/lo weight blocks (precision 1, 2)
     char* d_wlp = nullptr;                   // [layers][WP_LAYER_BYTES] 32x32x16 fragments of the ping-pong bf16 kernel (precision 2)
     float* d_wc16 = nullptr;                 // compression weights in the channel order of a 16-byte bf16 load of h
+    float *d_wpool = nullptr, *d_cols = nullptr, *d_cp = nullptr, *d_zero = nullptr;   // conv(read-mean): weights [segment][128][384], scratch, result
     bool use_p = false;                      // precision 2 on dan_kernels_bf16p.hip: y and h cross HBM as bf16
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
@@ -358,6 +359,7 @@ int dan_finalize(dan_t* h) {
         h->use_p = ok;
     }
     std::vector<char> wlp(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
+    std::vector<float> wpool_all(h->use_p ? (size_t)h->n_segments * CPAD * 3 * CPAD : 0, 0.f);
     std::vector<float> wc16_all;
     const size_t wc16_layer = (size_t)L * 2 * 64 * 8;        // [pos][n 2][lane 64][8]
     if (h->use_p && H > 0) wc16_all.resize((size_t)c.layers * wc16_layer);
@@ -405,6 +407,14 @@ int dan_finalize(dan_t* h) {
         }
         char* blkp = h->use_p ? wlp.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
         if (blkp) pack_fragp((uint16_t*)(blkp + WP_CONV_OFF), 3, l == 0 ? P_KS0 : P_KSC, 4, Wf);
+        if (blkp && l > 0)
+            for (int sg = 1; sg < h->n_segments; ++sg)
+                if (h->seg_begin[sg] == l) {                     // the layer behind a pool layer: its bf16-rounded weights, [o][t * 128 + c]
+                    float* wp = wpool_all.data() + (size_t)sg * CPAD * 3 * CPAD;
+                    for (int o = 0; o < CPAD; ++o)
+                        for (int t = 0; t < 3; ++t)
+                            for (int cc = 0; cc < CPAD; ++cc) wp[((size_t)o * 3 + t) * CPAD + cc] = bf16_float(bf16_bits(Wf(o, cc, t)));
+                }
         float* cst = blk + CST_OFF;
         for (int o = 0; o < cout; ++o) { cst[CST_BIAS + o] = b->data[o]; cst[CST_SCALE + o] = 1.f; }
         if (c.use_bn) {                                      // eval-mode BN after the ReLU, eps 1e-5 (model.py:750-751)
@@ -474,6 +484,11 @@ int dan_finalize(dan_t* h) {
                    CST_FLOATS * sizeof(float));
         if ((rc = dev_upload(h, &h->d_wlp, wlp))) return rc;
         if (H > 0 && (rc = dev_upload(h, &h->d_wc16, wc16_all))) return rc;
+        if (h->n_segments > 1) {
+            if ((rc = dev_upload(h, &h->d_wpool, wpool_all))) return rc;
+            std::vector<float> zeros(CPAD, 0.f);
+            if ((rc = dev_upload(h, &h->d_zero, zeros))) return rc;
+        }
     }
     if (c.precision) {                                       // constants are shared: copy each layer's fp32 block tail
         for (int l = 0; l < c.layers; ++l)
@@ -516,6 +531,10 @@ int dan_finalize(dan_t* h) {
     const size_t read_floats = (size_t)L * CPAD;
     if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats))) return rc;
     if ((rc = dev_alloc(h, &h->d_pool, (size_t)h->chunk * read_floats))) return rc;
+    if (h->use_p && h->n_segments > 1) {
+        if ((rc = dev_alloc(h, &h->d_cp, (size_t)h->chunk * read_floats))) return rc;
+        if ((rc = dev_alloc(h, &h->d_cols, (size_t)h->chunk * L * 3 * CPAD))) return rc;
+    }
     if (c.skip_empty_rows) {
         float* tmp = nullptr;
         if ((rc = dev_alloc(h, &tmp, (size_t)h->chunk * R))) return rc;     // int32 per pileup row
@@ -610,7 +629,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                     b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
                     b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
-                    b.y = (uint16_t*)h->d_y; b.pool = a.pool; b.h = (uint16_t*)h->d_h; b.h_layer_stride = a.h_layer_stride;
+                    b.y = (uint16_t*)h->d_y; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = (uint16_t*)h->d_h; b.h_layer_stride = a.h_layer_stride;
                     b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
                     launch_segmentp(b, ns, h->n_cus, s);
                 } else {
@@ -625,8 +644,12 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-                    if (h->use_p) launch_read_mean16((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
-                    else launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                    if (h->use_p) {
+                        launch_read_mean16((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                        const int ln = h->seg_begin[sg + 1];                      // 0-based layer behind the pool: its dilation
+                        launch_conv_pool(h->d_pool, h->d_wpool + (size_t)(sg + 1) * CPAD * 3 * CPAD, h->d_zero, h->d_cols, h->d_cp, ns, L,
+                                         ln + 1 < c.layers ? c.dil_mid : c.dil_final, s);
+                    } else launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
                     rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
                     HIPCHK(h, hipGetLastError());            // a refused launch must not let garbage flow on to the FC
                 }

@@ -147,7 +147,7 @@ struct SegmentPArgs {
     const float* emb;
     const float* pe;
     uint16_t* y;                 // bf16 [site][read][L][CPAD]   in/out
-    const float* pool;           // fp32 [site][L][CPAD] or nullptr
+    const float* pool;           // fp32 [site][L][CPAD]: conv(read-mean) of the segment's first layer (launch_conv_pool), or nullptr
     uint16_t* h;                 // bf16 [layer][site][read][L][HPAD] or nullptr
     long long h_layer_stride;    // elements between layers of h
     float* tap;                  // fp32 [site][read][L][CPAD] or nullptr
@@ -160,6 +160,10 @@ struct SegmentPArgs {
 // true if the structure can run on this kernel (else the eight-wave / two-workgroup kernels take it)
 bool segmentp_supports(int L, int l_begin, unsigned res_mask, bool has_pool);
 void launch_segmentp(const SegmentPArgs& a, int n_sites, int n_cus, hipStream_t s);
+// cp[site][p][o] = sum_{t,c} wpool[o][t * 128 + c] * pool[site][p + (t - 1) dil][c]: the read-mean's share of the convolution
+// behind a pool layer, in fp32 (wpool: that layer's bf16-rounded weights; cols: [n_sites * L][384] scratch; zero_bias: 128 zeros)
+void launch_conv_pool(const float* pool, const float* wpool, const float* zero_bias, float* cols, float* cp, int n_sites, int L,
+                      int dil, hipStream_t s);
 // bf16-input forms of the three reductions
 void launch_read_mean16(const uint16_t* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s);
 void launch_final_pool16(const uint16_t* y, float* feat, long long feat_stride, int n_sites, int R, int L, int C,

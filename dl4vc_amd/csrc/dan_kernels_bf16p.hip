@@ -29,6 +29,25 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(1))) bf8* gbf8p;
 
+// compile-time fence: nothing is scheduled across it.  Without one behind each GEMM hipcc hoists the epilogue's LDS reads (32
+// registers of BatchNorm constants) above the GEMM and spills them inside it
+#define PFENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef DAN_STAMPS
+// diagnostic build only (tools/segp_probe.hip): s_memtime stamps of the THIRD row a workgroup walks (steady state), per wave
+__device__ unsigned long long* g_pstamps;
+#define PSTAMP(k_)                                                                                    \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
+        if (lane == 0 && k == jw + 2 * nj && (k_) < 64) g_pstamps[((size_t)blockIdx.x * NWAVE + wave) * 64 + (k_)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define PSTAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ v16f mfma32(bf8 a, bf8 b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 
@@ -39,53 +58,55 @@ __device__ __forceinline__ unsigned cell_addr(int row, int chunk) { return (unsi
 // acc[m] += W(this wave's 32 channels) x X(32 positions of tile m) over TAPS x KS k-steps of 16 channels.
 //   xb0..2: this lane's byte address of chunk (lane >> 5) of its row for tap t in the source image (tile 0); chunk
 //           2 ks + (lane >> 5) lies at xb ^ (ks << 5), tile m a further m * 32 rows on.
-//   w:      this wave's first fragment (+ lane); step (t, ks) is (t * P_KSC + ks) * 4 fragments on.
+//   w:      this wave's first fragment (+ lane); step (t, ks) is (t * P_KSC + ks) * 4 fragments on; first[] = steps 0..3.
 // A run-time loop over chunks of NA = 4 k-steps: the four weight fragments of the NEXT chunk are requested slot by slot as
 // the current chunk's are consumed (an L2 round trip = 4 x MT MFMAs ahead), the activations of the next k-step while the
 // current one's MFMAs issue (double-buffered registers, one ds_read_b128 behind each MFMA).
-template <int MT, int TAPS, int KS>
-__device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8p w) {
-    constexpr int NA = 4;
-    static_assert(KS % NA == 0, "k-steps per tap come in chunks of four");
-    constexpr int CH = KS / NA, NCH = TAPS * CH;
+template <int MT, int TAPS>
+__device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8p w,
+                                       const bf8 (&first)[4]) {
+    // Fully unrolled over TAPS x 8 k-steps (hipcc then counts its vmcnt waits exactly: a run-time chunk loop drained every
+    // outstanding weight fragment once per chunk).  ONE shape serves layer 1 too -- its 48 input channels run as 128 with zero
+    // weights -- because a second conv instance kept a second set of 80 accumulator registers alive.
+    constexpr int NA = 4, S = TAPS * P_KSC;
     bf8 a[NA], b[2][MT];
 #pragma unroll
-    for (int j = 0; j < NA; ++j) a[j] = w[j * 4 * 64];
+    for (int j = 0; j < NA; ++j) a[j] = first[j];               // (requested by the caller a stage ahead: an L2 round trip)
 #pragma unroll
     for (int m = 0; m < MT; ++m) b[0][m] = lds_read(lds, xb0 + m * (32 * P_ROW_BYTES));
-    unsigned xcur = xb0;
-    int ks0 = 0;                                                 // first k-step of the current chunk within its tap
-    gbf8p wp = w;
-    for (int c = 0; c < NCH; ++c) {
-        const int cn = c + 1;
-        const bool last = cn == NCH;
-        unsigned xnext = xcur;
-        int ksn = ks0 + NA;
-        gbf8p wn = wp + NA * 4 * 64;
-        if (ksn == KS) {                                         // the next chunk opens the next tap
-            ksn = 0;
-            wn += (P_KSC - KS) * 4 * 64;
-            if (TAPS == 3) xnext = (cn == CH) ? xb1 : xb2;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int sn = s + 1;
+        const unsigned xt = (sn / P_KSC == 0) ? xb0 : (sn / P_KSC == 1) ? xb1 : xb2;
+        const unsigned xa = xt ^ (unsigned)((sn % P_KSC) << 5);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = mfma32(a[s % NA], b[s & 1][m], acc[m]);
+            if (sn < S) b[sn & 1][m] = lds_read(lds, xa + m * (32 * P_ROW_BYTES));
         }
-        if (last) { wn = wp; xnext = xcur; ksn = ks0; }          // (uniform) nothing follows: re-request what is at hand
+        // the slot's next fragment is requested BEHIND the MFMAs that read the slot (in program order): it may land in the same
+        // registers
+        if (s + NA < S) a[s % NA] = w[(size_t)(s + NA) * 4 * 64];
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const bf8 as = a[j];
-            a[j] = wn[j * 4 * 64];
-            const unsigned xa = (j + 1 < NA) ? (xcur ^ (unsigned)((ks0 + j + 1) << 5)) : (xnext ^ (unsigned)(ksn << 5));
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                acc[m] = mfma32(as, b[j & 1][m], acc[m]);
-                b[(j + 1) & 1][m] = lds_read(lds, xa + m * (32 * P_ROW_BYTES));
-            }
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
+        for (int m = 0; m < MT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (sn < S) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        xcur = xnext; ks0 = ksn; wp = wn;
+        if (s + NA < S) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+}
+
+__device__ __forceinline__ void load_first(bf8 (&f)[4], gbf8p w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = w[j * 4 * 64];
+}
+
+__device__ __forceinline__ void load16(v16f& v, const float* p) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const v4f t = *(const v4f*)(p + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
     }
 }
 
@@ -95,20 +116,81 @@ __device__ __forceinline__ void pack16(const v16f& v, bf8& lo, bf8& hi) {
     for (int j = 0; j < 8; ++j) { lo[j] = (__bf16)v[j]; hi[j] = (__bf16)v[8 + j]; }
 }
 
+// h = relu(Wb * y + bb), 128 -> 32 (model.py:774) from image `img`, position tiles of 32 dealt over waves 0 .. NW-1; every
+// activation fragment of the wave's tiles is requested before the first MFMA (the conv accumulators are dead here: registers
+// are plentiful), the tiles' chains interleave.  wb, bb: the layer's eight weight fragments and this lane's 16 biases (requested
+// by the caller a stage ahead).
+template <int MT, int NW>
+__device__ __forceinline__ void bottleneck_p(const char* img, const bf8 (&wb)[P_KSC], const v16f& bb, uint16_t* hrow, int L,
+                                             int wave, int lane) {
+    constexpr int NTL = (2 * MT + NW - 1) / NW;
+    asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop: they spilled)
+    const int n = lane & 31, hh = lane >> 5;
+    const unsigned xa0 = cell_addr(P_HALO + n, hh);              // 32 rows further on the swizzle repeats: tile tl lies tl * 8 KiB on
+    bf8 bx[2][P_KSC];                                            // the next tile's fragments are requested under this tile's MFMAs
+    auto fetch = [&](int i, bf8 (&dst)[P_KSC]) {
+        const int tl = min(wave + NW * i, 2 * MT - 1);
+        const char* tile = img + tl * (32 * P_ROW_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < P_KSC; ++ks) dst[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 5));
+    };
+    fetch(0, bx[0]);
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        if (i + 1 < NTL) fetch(i + 1, bx[(i + 1) & 1]);
+        v16f hacc = bb;
+#pragma unroll
+        for (int ks = 0; ks < P_KSC; ++ks) hacc = mfma32(wb[ks], bx[i & 1][ks], hacc);
+        const int tl = wave + NW * i, p = 32 * tl + n;
+        if (tl < 2 * MT && p < L) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hacc[j] = relu1(hacc[j]);
+            bf8 lo, hi;
+            pack16(hacc, lo, hi);
+            bf8* o = (bf8*)(hrow + (size_t)p * HPAD + 16 * hh);
+            o[0] = lo;
+            o[1] = hi;
+        }
+    }
+}
+
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_base + 16 * lane (no registers, asynchronous; counted in vmcnt)
+// Issued as inline assembly, not through __builtin_amdgcn_global_load_lds: with the builtin in flight hipcc orders every later
+// ds_read behind it (it cannot see that the DMA fills the OTHER image) and waits vmcnt(0) -- an HBM round trip -- at the first
+// LDS read of the stage that was meant to run under the transfer.  hipcc does not count an asm load (its own vmcnt waits only
+// become more conservative: memory returns in order); the consumer waits vmcnt(0) explicitly before the barrier that
+// publishes the image.  M0 = the wave-uniform LDS byte address; saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* src, char* lds_base) {
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+__device__ __forceinline__ void lds16(v16f& v, const float* p) {        // 16 consecutive floats from LDS
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const v4f t = *(const v4f*)(p + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+}
+
 template <int MT>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(SegmentPArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[P_LDS_BYTES];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int q = wave & 3, half = wave >> 2;
-    const int n = lane & 31, hh = lane >> 5;
     const int L = a.L;
     const int pbase = half * (MT * 32);
+    // behind the two images: the per-channel constants (bias, scale, shift, bres: 512 floats) of the current layer and of the
+    // next one, staged a layer ahead by waves 0-1 -- a constant costs an LDS read where it is needed, not an L2 round trip
+    auto cbuf = [&](int l) { return (float*)(lds + 2 * P_IMG_BYTES + (l & 1) * 2048); };
 
     // zero both images and the tail once: the halo rows, the rows past the window and the bytes a last tile reads beyond its
-    // image are never written with anything but zeros afterwards (see the epilogue's mask)
-    for (int i = tid; i < P_LDS_BYTES / 16; i += SEG_THREADS) *(v4f*)(lds + (size_t)i * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+    // image are never written with anything but zeros (or, in the tail, finite constants) afterwards (see the epilogue's mask)
+    for (int i = tid0; i < P_LDS_BYTES / 16; i += SEG_THREADS) *(v4f*)(lds + (size_t)i * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     // persistent walk: workgroups b and b + 8 share an XCD (round-robin dealing), so slice x = b & 7 of the rows -- whole sites --
@@ -116,91 +198,119 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
     const int n_work = a.work_count ? *a.work_count : a.n_rows;
     const int slice = a.work_count ? (n_work + 7) / 8 : a.slice_rows;
     const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, nj = gridDim.x >> 3;
-    for (int k = jw; k < slice; k += nj) {
+    auto row_of = [&](int k) {                                   // row index of this workgroup's k-th slice entry, -1 past the end
         const int wk = xcd * slice + k;
-        if (wk >= n_work) break;
-        const int row_index = __builtin_amdgcn_readfirstlane(a.work_count ? a.work[wk] : wk);
+        if (k >= slice || wk >= n_work) return -1;
+        return a.work_count ? a.work[wk] : wk;
+    };
+    const bool resumed = a.l_begin > 0;
+    // a resumed segment's input: the read's bf16 image y, copied by LDS-DMA into the image that is free (each 1-KiB piece = 4
+    // rows; the chunk swizzle goes on the per-lane SOURCE address, the destination is lane-linear), requested a row ahead
+    auto dma_read = [&](int row_index, int img_i, int lane) {
+        const char* ysrc = (const char*)(a.y + (size_t)row_index * (size_t)L * CPAD);
+        char* img = lds + img_i * P_IMG_BYTES + P_HALO * P_ROW_BYTES;
+        for (int kb = wave; kb * 4 < L; kb += NWAVE) {
+            const int p = 4 * kb + (lane >> 4), r = P_HALO + p;
+            if (p < L) glds16(ysrc + (size_t)p * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
+        }
+    };
+    // ... and the seed of its first layer's accumulators: conv(pool) of the read's site (launch_conv_pool), the read-mean's share
+    // of conv(y + pool) (model.py:742) -- the kernel convolves y alone
+    v16f acc[MT];
+    auto seed_request = [&](int row_index, int lane) {
+        const int n = lane & 31, hh = lane >> 5;
+        const float* cp = a.pool + (size_t)(row_index / a.R) * (size_t)L * CPAD + 32 * q + 16 * hh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int p = pbase + 32 * m + n;
+            if (p < L) load16(acc[m], cp + (size_t)p * CPAD);
+            else acc[m] = (v16f)(0.f);
+        }
+    };
+    int dma_img = 0;
+    if (resumed) {
+        const int r0 = __builtin_amdgcn_readfirstlane(row_of(jw));
+        if (r0 >= 0) {
+            dma_read(r0, 0, tid0 & 63);
+            if (a.pool) seed_request(r0, tid0 & 63);
+        }
+    }
+
+    for (int k = jw; k < slice; k += nj) {
+        const int row_index = __builtin_amdgcn_readfirstlane(row_of(k));
+        if (row_index < 0) break;
+        const int next_row = __builtin_amdgcn_readfirstlane(row_of(k + nj));
+        // (an opaque copy of the thread index per row: hipcc otherwise forms every per-lane address of the row body ahead of the
+        // row loop and keeps them -- spilled -- through all of it)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int n = lane & 31, hh = lane >> 5;
         const int site = row_index / a.R;
         const size_t read_idx = (size_t)row_index;
-        int cur = 0;                                             // image holding the current layer input
-        {
+        int cur = resumed ? dma_img : 0;                         // image holding the current layer input
+        auto blk_of = [&](int l) { return a.wl + (size_t)l * WP_LAYER_BYTES; };
+        // constants of layer l: requested by threads 0..127 (one 16-byte load each), put into cbuf(l) a stage later
+        v4f creq;
+        auto cst_request = [&](int l) { if (tid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WP_CST_OFF) + tid * 4); };
+        auto cst_put = [&](int l) { if (tid < 128) *(v4f*)(cbuf(l) + tid * 4) = creq; };
+        PSTAMP(0);
+        cst_request(a.l_begin);
+        const int c0 = 32 * q + 16 * hh;                          // this lane's 16 output channels
+        const int row0 = P_HALO + pbase + n;                      // its row in tile 0
+        const unsigned wa = cell_addr(row0, 4 * q + 2 * hh);      // its two output chunks: wa, wa ^ 16
+        bf8 pre_a[4];
+        load_first(pre_a, (gbf8p)(blk_of(a.l_begin) + WP_CONV_OFF) + q * 64 + lane);
+        if (!resumed) {
             char* img = lds;                                     // image 0
-            if (a.l_begin == 0) {
-                // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, rounded to bf16
-                const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
-                int ok_ref = 1, ok_var = 1;
-                for (int p = tid; p < L; p += SEG_THREADS) {
-                    const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
-                    ok_ref &= (rm == 0) || (tok == rm);
-                    ok_var &= (vm == 0) || (tok == vm);
-                }
-                // workgroup-wide AND through eight flag words at the very end of the array (__syncthreads_and would add its own
-                // LDS on top of the 160 KiB this kernel declares)
-                int* flags = (int*)(lds + P_LDS_BYTES - 64);
-                {
-                    const int w_ref = __all(ok_ref), w_var = __all(ok_var);
-                    if (lane == 0) { flags[wave] = w_ref; flags[8 + wave] = w_var; }
-                }
-                __syncthreads();
-                int agree_ref = 1, agree_var = 1;
+            // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, rounded to bf16
+            const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+            int ok_ref = 1, ok_var = 1;
+            for (int p = tid; p < L; p += SEG_THREADS) {
+                const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+                ok_ref &= (rm == 0) || (tok == rm);
+                ok_var &= (vm == 0) || (tok == vm);
+            }
+            // workgroup-wide AND through sixteen flag words (__syncthreads_and would add its own LDS on top of the 160 KiB this
+            // kernel declares); they sit in the constants buffer that is not in use at a row's start
+            int* flags = (int*)cbuf(a.l_begin + 1);
+            {
+                const int w_ref = __all(ok_ref), w_var = __all(ok_var);
+                if (lane == 0) { flags[wave] = w_ref; flags[8 + wave] = w_var; }
+            }
+            __syncthreads();
+            int agree_ref = 1, agree_var = 1;
 #pragma unroll
-                for (int w8 = 0; w8 < NWAVE; ++w8) { agree_ref &= flags[w8]; agree_var &= flags[8 + w8]; }
-                for (int p = tid; p < L; p += SEG_THREADS) {
-                    const int tok = a.reads[rbase + p], qv = a.qual[rbase + p], st = a.strand[rbase + p];
-                    const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
-                    const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
-                    const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
-                    const float* pp = a.pe + p * EMBED;
-                    float row[CIN0];
+            for (int w8 = 0; w8 < NWAVE; ++w8) { agree_ref &= flags[w8]; agree_var &= flags[8 + w8]; }
+            for (int p = tid; p < L; p += SEG_THREADS) {
+                const int tok = a.reads[rbase + p], qv = a.qual[rbase + p], st = a.strand[rbase + p];
+                const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+                const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
+                const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
+                const float* pp = a.pe + p * EMBED;
+                float row[CIN0];
 #pragma unroll
-                    for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
-                    row[40] = (float)qv * 0.01f;
-                    row[41] = (float)st * 0.5f;
-                    row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
-                    row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
-                    row[44] = (rm != 0) ? 1.f : 0.f;
-                    row[45] = row[46] = row[47] = 0.f;
-                    const int r = P_HALO + p;
+                for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
+                row[40] = (float)qv * 0.01f;
+                row[41] = (float)st * 0.5f;
+                row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
+                row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
+                row[44] = (rm != 0) ? 1.f : 0.f;
+                row[45] = row[46] = row[47] = 0.f;
+                const int r = P_HALO + p;
 #pragma unroll
-                    for (int c = 0; c < CIN0 / 8; ++c) {
-                        bf8 v;
+                for (int c = 0; c < CPAD / 8; ++c) {             // channels 48..127 as zeros: layer 1 runs as a 128-channel layer
+                    bf8 v;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (__bf16)row[c * 8 + j];
-                        lds_write(img, cell_addr(r, c), v);
-                    }
-                }
-            } else {
-                // ---- resume: x = bf16(y + pool) (model.py:742); the whole read and its site's pool image in flight at once
-                const bf8* ysrc = (const bf8*)(a.y + read_idx * (size_t)L * CPAD);
-                const v4f* psrc = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
-                const int n16 = L * (CPAD / 8);
-                constexpr int NPF = (P_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;
-                bf8 vy[NPF];
-                v4f vp[NPF][2];
-#pragma unroll
-                for (int u = 0; u < NPF; ++u) {
-                    const int i = tid + u * SEG_THREADS;
-                    if (i < n16) vy[u] = ysrc[i];
-                }
-#pragma unroll
-                for (int u = 0; u < NPF; ++u) {
-                    const int i = tid + u * SEG_THREADS;
-                    vp[u][0] = vp[u][1] = (v4f){0.f, 0.f, 0.f, 0.f};
-                    if (psrc && i < n16) { vp[u][0] = psrc[2 * i]; vp[u][1] = psrc[2 * i + 1]; }
-                }
-#pragma unroll
-                for (int u = 0; u < NPF; ++u) {
-                    const int i = tid + u * SEG_THREADS;
-                    if (i < n16) {
-                        bf8 v;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (__bf16)((float)vy[u][j] + vp[u][j >> 2][j & 3]);
-                        lds_write(img, cell_addr(P_HALO + (i >> 4), i & 15), v);
-                    }
+                    for (int j = 0; j < 8; ++j) v[j] = (c * 8 + j < CIN0) ? (__bf16)row[(c * 8 + j) % CIN0] : (__bf16)0.f;
+                    lds_write(img, cell_addr(r, c), v);
                 }
             }
         }
+        cst_put(a.l_begin);
+        if (resumed) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): this wave's pieces of the DMA'd image have landed
         __syncthreads();
+        PSTAMP(1);
 
         auto copy_tap = [&](int img_i, int nch) {
             // image -> fp32 [L][CPAD] (debug tap)
@@ -216,55 +326,65 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                 *(v4f*)(dst + (size_t)i * 8 + 4) = o1;
             }
         };
-        if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_tap(0, CIN0);
+        if (a.tap && a.tap_layer == 0 && !resumed) copy_tap(0, CIN0);
 
         for (int l = a.l_begin; l < a.l_end; ++l) {
-            const char* blk = a.wl + (size_t)l * WP_LAYER_BYTES;
-            const float* cst = (const float*)(blk + WP_CST_OFF);
+            const char* blk = blk_of(l);
+            const float* lc = cbuf(l);
             const bool residual = (a.res_mask >> l) & 1u;
+            const bool last_layer = l + 1 == a.l_end;
+            const bool defer = a.has_hw && l > a.l_begin;          // layer l-1's bottleneck runs behind this layer's epilogue
             const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
             const char* src = lds + cur * P_IMG_BYTES;
             char* dst = lds + (cur ^ 1) * P_IMG_BYTES;
-            const int c0 = 32 * q + 16 * hh;                      // this lane's 16 output channels
-            const int row0 = P_HALO + pbase + n;                  // its row in tile 0
+            [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+            PSTAMP(sb + 0);
+            PFENCE();
+            if (!last_layer) cst_request(l + 1);
 
-            v16f acc[MT];
             {
                 v16f bias;
+                lds16(bias, lc + CST_BIAS + c0);
+                if (l == a.l_begin && resumed && a.pool) {       // seeded with conv(pool) of the site (requested a row ahead)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const v4f bv = *(const v4f*)(cst + CST_BIAS + c0 + 4 * g);
+                    for (int m = 0; m < MT; ++m) acc[m] += bias;
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bias[4 * g + j] = bv[j];
+                    for (int m = 0; m < MT; ++m) acc[m] = bias;
                 }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = bias;
             }
             const unsigned xb0 = cell_addr(row0 - dil, hh), xb1 = cell_addr(row0, hh), xb2 = cell_addr(row0 + dil, hh);
             gbf8p wconv = (gbf8p)(blk + WP_CONV_OFF) + q * 64 + lane;
-            // layer 1: 48 encoded channels as four k-steps (the fourth meets zero weights; whatever finite values an earlier
-            // layer left in chunks 6, 7 of the image contribute exactly 0)
-            if (l == 0) gemm_p<MT, 3, 4>(acc, src, xb0, xb1, xb2, wconv);
-            else        gemm_p<MT, 3, P_KSC>(acc, src, xb0, xb1, xb2, wconv);
+            // (layer 1: the 48 encoded channels run as 128 -- zero weights beyond them, zeros in the image: see the encode stage)
+            gemm_p<MT, 3>(acc, src, xb0, xb1, xb2, wconv, pre_a);
+            PFENCE();
+            PSTAMP(sb + 1);
 
             // ---- epilogue: ReLU, BatchNorm (folded), rows past the window forced to zero, bf16, two 16-byte stores per tile
-            const unsigned wa = cell_addr(row0, 4 * q + 2 * hh);
+            bf8 wb[P_KSC];
+            v16f bb;
+            auto bottleneck_request = [&](int lb) {              // layer lb's bottleneck weights and this lane's biases
+                gbf8p wbot = (gbf8p)(blk_of(lb) + WP_BOT_OFF) + lane;
+#pragma unroll
+                for (int ks = 0; ks < P_KSC; ++ks) wb[ks] = wbot[ks * 64];
+                load16(bb, (const float*)(blk_of(lb) + WP_CST_OFF) + CST_BBOT + 16 * hh);
+            };
             {
-                const float* cst2 = cst;
-                asm volatile("" : "+s"(cst2));                   // (requested here, not ahead of the GEMM: 32 registers)
                 v16f sc, sh;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const v4f s4 = *(const v4f*)(cst2 + CST_SCALE + c0 + 4 * g), h4 = *(const v4f*)(cst2 + CST_SHIFT + c0 + 4 * g);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { sc[4 * g + j] = s4[j]; sh[4 * g + j] = h4[j]; }
-                }
+                lds16(sc, lc + CST_SCALE + c0);
+                lds16(sh, lc + CST_SHIFT + c0);
+                if (defer) bottleneck_request(l - 1);
+                else if (a.has_hw && last_layer && !residual) bottleneck_request(l);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int p = pbase + 32 * m + n;
                     v16f v = acc[m];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = (p < L) ? relu1(v[i]) * sc[i] + sh[i] : 0.f;
+                    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]) * sc[i] + sh[i];
+                    if (pbase + 32 * m + 32 > L) {               // (uniform) the tile reaches past the window
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
+                    }
                     bf8 lo, hi;
                     pack16(v, lo, hi);
                     if (p < P_LMAX + P_HALO) {
@@ -273,35 +393,53 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                     }
                 }
             }
+            // the first fragments of the next GEMM (this layer's residual 1x1, else the next layer's conv) ride under the barrier
+            // wait; the next layer's constants go to their buffer
+            {
+                const char* nb = residual ? blk : blk_of(last_layer ? l : l + 1);
+                load_first(pre_a, (gbf8p)(nb + (residual ? WP_RES_OFF : WP_CONV_OFF)) + q * 64 + lane);
+            }
+            if (!last_layer) cst_put(l + 1);
+            PFENCE();
+            PSTAMP(sb + 2);
+            // ---- layer l-1's bottleneck, from the image this layer's GEMM has just read (no barrier of its own: the image stays
+            // intact until the barrier below)
+            if (defer) {
+                bottleneck_p<MT, NWAVE>(src, wb, bb, a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+                if (a.has_hw && last_layer && !residual) bottleneck_request(l);   // (these four waves' registers were taken)
+            }
+            PSTAMP(sb + 7);
             __syncthreads();
+            PFENCE();
+            PSTAMP(sb + 3);
             if (residual) {
                 // y = Wr * t + bres + x   (model.py:753-761): t = the image just written, x = this lane's own cells of the input image
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const bf8 xl = lds_read(src, wa + m * (32 * P_ROW_BYTES)), xh = lds_read(src, (wa ^ 16u) + m * (32 * P_ROW_BYTES));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { acc[m][j] = (float)xl[j]; acc[m][8 + j] = (float)xh[j]; }
-                }
                 {
                     v16f br;
+                    lds16(br, lc + CST_BRES + c0);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const v4f bv = *(const v4f*)(cst + CST_BRES + c0 + 4 * g);
+                    for (int m = 0; m < MT; ++m) {
+                        const bf8 xl = lds_read(src, wa + m * (32 * P_ROW_BYTES)), xh = lds_read(src, (wa ^ 16u) + m * (32 * P_ROW_BYTES));
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) br[4 * g + j] = bv[j];
+                        for (int j = 0; j < 8; ++j) { acc[m][j] = (float)xl[j] + br[j]; acc[m][8 + j] = (float)xh[j] + br[8 + j]; }
                     }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] += br;
                 }
                 gbf8p wres = (gbf8p)(blk + WP_RES_OFF) + q * 64 + lane;
-                gemm_p<MT, 1, P_KSC>(acc, dst, xb1, xb1, xb1, wres);
+                PFENCE();
+                gemm_p<MT, 1>(acc, dst, xb1, xb1, xb1, wres, pre_a);
+                PFENCE();
+                PSTAMP(sb + 4);
+                load_first(pre_a, (gbf8p)(blk_of(last_layer ? l : l + 1) + WP_CONV_OFF) + q * 64 + lane);
+                if (a.has_hw && last_layer) bottleneck_request(l);
                 char* back = lds + cur * P_IMG_BYTES;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int p = pbase + 32 * m + n;
                     v16f v = acc[m];
+                    if (pbase + 32 * m + 32 > L) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
+                        for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
+                    }
                     bf8 lo, hi;
                     pack16(v, lo, hi);
                     if (p < P_LMAX + P_HALO) {
@@ -310,54 +448,35 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                     }
                 }
                 __syncthreads();
+                PFENCE();
+                PSTAMP(sb + 5);
             } else {
                 cur ^= 1;
             }
             if (a.tap && a.tap_layer == l + 1) copy_tap(cur, CPAD);
-
-            // ---- bottleneck h = relu(Wb * y + bb), 128 -> 32 (model.py:774): position tiles dealt over the waves; reads the image
-            // the next layer's GEMM reads too, so no barrier follows it
-            if (a.has_hw) {
-                const char* img = lds + cur * P_IMG_BYTES;
-                gbf8p wbot = (gbf8p)(blk + WP_BOT_OFF) + lane;
-                uint16_t* hrow = a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD;
-                bf8 wb[P_KSC];
-#pragma unroll
-                for (int ks = 0; ks < P_KSC; ++ks) wb[ks] = wbot[ks * 64];
-                v16f bb;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const v4f bv = *(const v4f*)(cst + CST_BBOT + 16 * hh + 4 * g);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bb[4 * g + j] = bv[j];
-                }
-                for (int tl = wave; tl * 32 < L; tl += NWAVE) {
-                    const unsigned xa = cell_addr(P_HALO + 32 * tl + n, hh);
-                    bf8 bx[P_KSC];
-#pragma unroll
-                    for (int ks = 0; ks < P_KSC; ++ks) bx[ks] = lds_read(img, xa ^ (unsigned)(ks << 5));
-                    v16f hacc = bb;
-#pragma unroll
-                    for (int ks = 0; ks < P_KSC; ++ks) hacc = mfma32(wb[ks], bx[ks], hacc);
-                    const int p = 32 * tl + n;
-                    if (p < L) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) hacc[i] = relu1(hacc[i]);
-                        bf8 lo, hi;
-                        pack16(hacc, lo, hi);
-                        bf8* o = (bf8*)(hrow + (size_t)p * HPAD + 16 * hh);
-                        o[0] = lo;
-                        o[1] = hi;
-                    }
-                }
+            if (last_layer) {
+                // ---- the segment's last layer has nobody to defer to: its bottleneck is a stage of its own, all eight waves (its
+                // weights were requested ahead of the barrier above).  First (a resumed segment) the next row's image is requested
+                // into the image that is now free: nothing the bottleneck waits for is behind it in the queue
+                // every load hipcc tracks is retired HERE (they were requested ahead of the barrier: no wait in practice), so that
+                // it places no vmcnt wait inside the stage that runs under the DMA -- one there would wait for the DMA as well
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (resumed && next_row >= 0) { dma_img = cur ^ 1; dma_read(next_row, dma_img, lane); }
+                if (a.has_hw)
+                    bottleneck_p<MT, NWAVE>(lds + cur * P_IMG_BYTES, wb, bb, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD,
+                                            L, wave, lane);
             }
+            PSTAMP(sb + 6);
         }
-        // ---- the segment's output -> y (bf16, [L][CPAD])
+        PSTAMP(62);
+        // ---- the segment's output -> y (bf16, [L][CPAD]); behind it the next row's accumulator seed is requested
         {
             const char* img = lds + cur * P_IMG_BYTES;
             bf8* ydst = (bf8*)(a.y + read_idx * (size_t)L * CPAD);
             for (int i = tid; i < L * (CPAD / 8); i += SEG_THREADS) ydst[i] = lds_read(img, cell_addr(P_HALO + (i >> 4), i & 15));
         }
+        if (resumed && a.pool && next_row >= 0) seed_request(next_row, lane);
+        PSTAMP(63);
         __syncthreads();                                         // the next row re-uses both images
     }
 }
@@ -379,6 +498,28 @@ void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t
     const int need = ((a.slice_rows + 0) < 1 ? 1 : a.slice_rows) * 8;       // no more workgroups than rows per slice x 8
     if (wgs > need) wgs = need;
     hipLaunchKernelGGL((segmentp_kernel<5>), dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv(pool): the read-mean's share of the layer after a pool layer, once per site (model.py:742 adds the mean to every read
+// before the convolution; conv(y + pool) = conv(y) + conv(pool), and the second term is the same for all reads of a site).
+// cols[site * L + p][t * 128 + c] = pool[site][p + (t - 1) dil][c] (zero outside the window); the product with the layer's
+// bf16-rounded weights [128][384] runs on the fp32 FC GEMM (dan_kernels.hip).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_cols_kernel(const v4f* __restrict__ pool, v4f* __restrict__ cols, int L, int dil, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % 32), t = (int)((i / 32) % 3);
+    const long long sp = i / 96;                               // site * L + p
+    const int p = (int)(sp % L), ps = p + (t - 1) * dil;
+    cols[i] = (ps >= 0 && ps < L) ? pool[(sp - p + ps) * 32 + c4] : (v4f){0.f, 0.f, 0.f, 0.f};
+}
+
+void launch_conv_pool(const float* pool, const float* wpool, const float* zero_bias, float* cols, float* cp, int n_sites, int L,
+                      int dil, hipStream_t s) {
+    const long long n4 = (long long)n_sites * L * 96;
+    hipLaunchKernelGGL(pool_cols_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const v4f*)pool, (v4f*)cols, L, dil, n4);
+    launch_fc(cols, 3 * CPAD, wpool, 3 * CPAD, zero_bias, cp, CPAD, n_sites * L, CPAD, 3 * CPAD, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -172,20 +172,27 @@ def conv_layer(spec: OracleSpec, sd, l: int, x, pool=None, bf16: Optional[str] =
                   above.  Pinned against the live reference run with bf16-rounded weights and forward-pre-hooks that round
                   the inputs of those modules (tests/test_vs_live_reference.py).
       "storage":  "operands" plus the roundings of the HIP kernel's bf16 activation STORAGE (dan_kernels_bf16p.hip): a
-                  layer's output y_l, the BatchNorm output feeding the residual 1x1, the pool-added input of the next
-                  segment and the bottleneck h_l are held as bf16 -- so the residual branch adds the bf16 value of x and the
-                  read-mean averages bf16 values.  Each is one more rounding of a value "operands" rounds anyway at its next
+                  layer's output y_l, the BatchNorm output feeding the residual 1x1 and the bottleneck h_l are held as bf16 --
+                  so the residual branch adds the bf16 value of x and the read-mean averages bf16 values; the read-mean itself
+                  enters the next layer unrounded, as its own fp32 convolution (see below).  Each is one more rounding of a value "operands" rounds anyway at its next
                   use as an operand; the GPU parity test holds the kernel to THIS mode layer by layer."""
     assert bf16 in BF16_MODES
     rb = bf16_round if bf16 else (lambda t: t)
     st = bf16_round if bf16 == "storage" else (lambda t: t)
     _, _, dil = spec.layer_dims(l)
     residual = x                                                 # model.py:732 (before the pool add)
-    if pool is not None:
-        x = st(x + pool)                                         # model.py:742
     W = sd["conv1D_layers.%d.weight" % (l - 1)]
     b = sd["conv1D_layers.%d.bias" % (l - 1)]
-    x = F.relu(F.conv2d(rb(x), rb(W), b, padding=(0, dil), dilation=(1, dil)))     # model.py:749
+    if pool is not None and bf16 == "storage":
+        # the kernel convolves the stored bf16 y alone and seeds its accumulators with conv(pool) of the site, computed once per
+        # site in fp32 (launch_conv_pool): conv(y + pool) = conv(y) + conv(pool) with the SUM never rounded to bf16
+        x = F.conv2d(rb(x), rb(W), b, padding=(0, dil), dilation=(1, dil)) + \
+            F.conv2d(pool, rb(W), None, padding=(0, dil), dilation=(1, dil))
+    else:
+        if pool is not None:
+            x = x + pool                                         # model.py:742
+        x = F.conv2d(rb(x), rb(W), b, padding=(0, dil), dilation=(1, dil))
+    x = F.relu(x)                                                # model.py:749
     if spec.use_bn:                                              # eval-mode BN AFTER the ReLU, model.py:750-751
         p = "bn1D_layers.%d." % (l - 1)
         x = F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"],
