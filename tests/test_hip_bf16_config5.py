@@ -190,3 +190,23 @@ def test_chunking_and_empty_row_skipping_leave_every_bit_unchanged(run):
     b.close()
     for k in out:
         assert np.array_equal(got[k], out[k]), k
+
+
+def test_staggered_form_is_bit_identical_to_the_lockstep_form(run, monkeypatch):
+    """DAN_BF16_FORM=q runs the staggered form of the kernel (position halves one phase apart, each updating its own image in
+    place, a 32-column tile computed by both): the same sums in the same order for every column a half owns -- every output bit
+    agrees with the default lockstep form.  (Also a check of the halo bookkeeping: a column of the shared tile used one layer
+    too long would differ.)"""
+    cfg, sd, planes, taps, pool, hbuf, feat, out = run
+    monkeypatch.setenv("DAN_BF16_FORM", "q")
+    net = DanNet(cfg).load_state_dict(sd)
+    assert net.handle.query("bf16_pingpong") == 1
+    got = net.forward_u8(*planes, aux=True)
+    net.handle.set_tap(cfg.layers)
+    net.forward_u8(*planes)
+    B = planes[0].shape[0]
+    tap7 = net.handle.read_buffer("tap", B * R * L * 128).reshape(B, R, L, 128)
+    net.close()
+    assert np.array_equal(tap7, taps[cfg.layers])
+    for k in out:
+        assert np.array_equal(got[k], out[k]), k
