@@ -361,7 +361,7 @@ int dan_finalize(dan_t* h) {
     std::vector<char> wlp(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
     std::vector<float> wpool_all(h->use_p ? (size_t)h->n_segments * CPAD * 3 * CPAD : 0, 0.f);
     std::vector<float> wc16_all;
-    const size_t wc16_layer = (size_t)L * 2 * 64 * 8;        // [pos][n 2][lane 64][8]
+    const size_t wc16_layer = (size_t)L * 2 * 2 * 64 * 4;    // floats: [pos][n 2][plane 2][lane 64][8 bf16]
     if (h->use_p && H > 0) wc16_all.resize((size_t)c.layers * wc16_layer);
     std::vector<float> wc_all, bc_all((size_t)c.layers * HPAD, 0.f);
     const size_t wc_layer = (size_t)L * 2 * 2 * 64 * 4;      // [g = 2L][tile 2][lane 64][4]
@@ -466,14 +466,17 @@ int dan_finalize(dan_t* h) {
                         }
             for (int o = 0; o < H; ++o) bc_all[(size_t)l * HPAD + o] = bcm->data[o];
             if (h->use_p) {
-                float* d16 = wc16_all.data() + (size_t)l * wc16_layer;
-                size_t k = 0;
+                uint16_t* d16 = (uint16_t*)(wc16_all.data() + (size_t)l * wc16_layer);
                 for (int pp = 0; pp < L; ++pp)
                     for (int n = 0; n < 2; ++n)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int s8 = 0; s8 < 8; ++s8) {
                                 const int o = 16 * n + (lane & 15), cc = 8 * (lane >> 4) + s8;
-                                d16[k++] = (o < H && cc < H) ? wcm->data[((size_t)o * H + cc) * L + pp] : 0.f;
+                                const float w = (o < H && cc < H) ? wcm->data[((size_t)o * H + cc) * L + pp] : 0.f;
+                                const uint16_t hi = bf16_bits(w);
+                                const size_t base = (((size_t)pp * 2 + n) * 2) * 64 * 8;
+                                d16[base + (size_t)lane * 8 + s8] = hi;                                   // plane 0
+                                d16[base + 64 * 8 + (size_t)lane * 8 + s8] = bf16_bits(w - bf16_float(hi));   // plane 1
                             }
             }
         }
@@ -664,7 +667,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
             if (H > 0) {
                 rc = prof_begin(h, "highway", s, &ev); if (rc) return rc;
                 if (h->use_p)
-                    launch_highway16((const uint16_t*)h->d_h, h_layer_stride, h->d_wc16, (long long)L * 2 * 64 * 8, h->d_bc, feat,
+                    launch_highway16((const uint16_t*)h->d_h, h_layer_stride, h->d_wc16, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat,
                                      h->F_stride, 2 * c.c_final * L, ns, R, L, H, c.layers, h->d_rowsrc, s);
                 else
                     launch_highway(h->d_h, h_layer_stride, h->d_wc, (long long)L * 2 * 2 * 64 * 4, h->d_bc, feat, h->F_stride,

@@ -168,8 +168,8 @@ void launch_conv_pool(const float* pool, const float* wpool, const float* zero_b
 void launch_read_mean16(const uint16_t* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s);
 void launch_final_pool16(const uint16_t* y, float* feat, long long feat_stride, int n_sites, int R, int L, int C,
                          const int* row_src, hipStream_t s);
-// wc16: compression weights packed [layer][pos][n 2][lane 64][8]  (B fragments of v_mfma_f32_16x16x4_f32 for the channel order
-// a 16-byte bf16 load of h delivers: lane (o = lane & 15, kk = lane >> 4), element s -> Wc[16 n + o][8 kk + s][pos])
+// wc16: compression weights as bf16 hi / lo planes in MFMA 16x16x32 B-fragment order, [layer][pos][n 2][plane 2][lane 64][8 bf16]:
+// lane (o = lane & 15, kk = lane >> 4), element s -> Wc[16 n + o][8 kk + s][pos]; wc_layer_stride in floats (= L * 2 * 2 * 64 * 4)
 void launch_highway16(const uint16_t* h, long long h_layer_stride, const float* wc16, long long wc_layer_stride,
                       const float* bc, float* feat, long long feat_stride, int feat_off, int n_sites, int R, int L,
                       int H, int layers, const int* row_src, hipStream_t s);

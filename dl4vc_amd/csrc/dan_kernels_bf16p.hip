@@ -930,14 +930,18 @@ void launch_final_pool16(const uint16_t* y, float* feat, long long fs, int n_sit
     hipLaunchKernelGGL(final_pool16_kernel, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const bf8*)y, feat, fs, R, L, C, row_src);
 }
 
-// highway compression from bf16 h: the fp32 kernel's structure (one workgroup = 64 reads x 32 outputs, 8 waves split K, partial
-// tiles summed through LDS in wave order), a k-group = ONE position (32 channels): a lane's 16-byte load is channels 8 kk .. 8 kk + 7
-// of its read, eight fp32 MFMA k-steps; the weight fragments are packed in that channel order (dan_kernels.h).
+// highway compression from bf16 h on the bf16 matrix cores: the fp32 kernel's structure (one workgroup = 64 reads x 32 outputs, 8
+// waves split the positions, partial tiles summed through LDS in wave order), a k-group = ONE position (32 channels) = one
+// v_mfma_f32_16x16x32_bf16 per (read tile, output tile, weight plane): a lane's 16-byte load of h IS its A fragment (read
+// lane & 15, channels 8 (lane >> 4) ..), the compression weights come as two bf16 planes (hi = bf16(w), lo = bf16(w - hi): 16
+// mantissa bits, products exact, fp32 sums).  With fp32 MFMAs (16 per position and read tile instead of 4 at half the cycles
+// each) this kernel was matrix-bound at 3.2 TB/s of h; now it streams.
 constexpr int HW16_WAVES = 8;
 constexpr int HW16_RT = 4;
-__device__ __forceinline__ v4f mfma16f(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+typedef __bf16 hbf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v4f mfma16b(hbf8 a, hbf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-__global__ __launch_bounds__(512) void highway16_kernel(const uint16_t* __restrict__ h, long long hls, const v4f* __restrict__ wc,
+__global__ __launch_bounds__(512) void highway16_kernel(const uint16_t* __restrict__ h, long long hls, const hbf8* __restrict__ wc,
                                                         long long wcls, const float* __restrict__ bc, float* __restrict__ feat,
                                                         long long fs, int feat_off, int n_rows, int R, int L, int H,
                                                         const int* __restrict__ row_src) {
@@ -954,42 +958,41 @@ __global__ __launch_bounds__(512) void highway16_kernel(const uint16_t* __restri
         const int row = min(row0 + 16 * i + r16, n_rows - 1);
         arow[i] = h + (size_t)layer * hls + (size_t)(row_src ? row_src[row] : row) * K + kk * 8;
     }
-    const v4f* wl = wc + (size_t)layer * wcls + (size_t)lane * 2;
+    const hbf8* wl = wc + (size_t)layer * wcls + lane;       // [pos][n 2][plane 2][lane 64]
     v4f acc[HW16_RT][2];
 #pragma unroll
     for (int i = 0; i < HW16_RT; ++i) { acc[i][0] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (v4f){0.f, 0.f, 0.f, 0.f}; }
     constexpr int D = 4;                                    // positions in flight per wave
-    bf8 ar[D][HW16_RT];
-    v4f b0[D][2], b1[D][2];
+    hbf8 ar[D][HW16_RT], bw[D][4];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const int g = min(g_lo + d, g_hi - 1);
 #pragma unroll
-        for (int i = 0; i < HW16_RT; ++i) ar[d][i] = *(const bf8*)(arow[i] + (size_t)g * HPAD);
-        b0[d][0] = wl[((size_t)g * 2) * 128]; b0[d][1] = wl[((size_t)g * 2) * 128 + 1];
-        b1[d][0] = wl[((size_t)g * 2 + 1) * 128]; b1[d][1] = wl[((size_t)g * 2 + 1) * 128 + 1];
+        for (int i = 0; i < HW16_RT; ++i) ar[d][i] = *(const hbf8*)(arow[i] + (size_t)g * HPAD);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bw[d][j] = wl[((size_t)g * 4 + j) * 64];
     }
     for (int g = g_lo; g < g_hi; g += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            bf8 av[HW16_RT];
+            hbf8 av[HW16_RT], w4[4];
 #pragma unroll
             for (int i = 0; i < HW16_RT; ++i) av[i] = ar[d][i];
-            const v4f w00 = b0[d][0], w01 = b0[d][1], w10 = b1[d][0], w11 = b1[d][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4[j] = bw[d][j];
             const int gn = min(g + d + D, g_hi - 1);
 #pragma unroll
-            for (int i = 0; i < HW16_RT; ++i) ar[d][i] = *(const bf8*)(arow[i] + (size_t)gn * HPAD);
-            b0[d][0] = wl[((size_t)gn * 2) * 128]; b0[d][1] = wl[((size_t)gn * 2) * 128 + 1];
-            b1[d][0] = wl[((size_t)gn * 2 + 1) * 128]; b1[d][1] = wl[((size_t)gn * 2 + 1) * 128 + 1];
+            for (int i = 0; i < HW16_RT; ++i) ar[d][i] = *(const hbf8*)(arow[i] + (size_t)gn * HPAD);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[d][j] = wl[((size_t)gn * 4 + j) * 64];
             if (g + d < g_hi) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-#pragma unroll
-                    for (int i = 0; i < HW16_RT; ++i) {
-                        const float x = (float)av[i][s];
-                        acc[i][0] = mfma16f(x, s < 4 ? w00[s & 3] : w01[s & 3], acc[i][0]);
-                        acc[i][1] = mfma16f(x, s < 4 ? w10[s & 3] : w11[s & 3], acc[i][1]);
-                    }
+                for (int i = 0; i < HW16_RT; ++i) {
+                    acc[i][0] = mfma16b(av[i], w4[0], acc[i][0]);
+                    acc[i][0] = mfma16b(av[i], w4[1], acc[i][0]);
+                    acc[i][1] = mfma16b(av[i], w4[2], acc[i][1]);
+                    acc[i][1] = mfma16b(av[i], w4[3], acc[i][1]);
+                }
             }
         }
     }
@@ -1018,7 +1021,7 @@ void launch_highway16(const uint16_t* h, long long hls, const float* wc16, long 
                       int feat_off, int n_sites, int R, int L, int H, int layers, const int* row_src, hipStream_t s) {
     const int n_rows = n_sites * R;
     hipLaunchKernelGGL(highway16_kernel, dim3((n_rows + 16 * HW16_RT - 1) / (16 * HW16_RT), layers), dim3(512), 0, s, h, hls,
-                       (const v4f*)wc16, wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H, row_src);
+                       (const hbf8*)wc16, wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H, row_src);
 }
 
 }  // namespace dan
