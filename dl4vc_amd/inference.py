@@ -16,7 +16,10 @@ import numpy as np
 from .dataset import assemble_batch
 from .hdf5io import CandidateFile
 from .shard import shard_range
-from .vcf import scored_record
+from .vcf import scored_record, threshold_distance, FormatOptions, PIPELINE_OPTIONS
+
+
+NEAR_EPS = 1e-4
 
 
 class _Pipeline:
@@ -25,8 +28,9 @@ class _Pipeline:
     score with ``'%.8f' % tensor``, one D2H sync per scalar, utils.py:168-178 -- and the loader hand-off overlap the
     forward.  A model without the asynchronous pair (the CPU test double) is called synchronously."""
 
-    def __init__(self, net, write, use_var_type_threshold):
+    def __init__(self, net, write, use_var_type_threshold, stats=None):
         self.net, self.write, self.vt_thr = net, write, use_var_type_threshold
+        self.stats = stats
         self.pending = None
         self.async_ok = hasattr(net, "forward_u8_async")
         self.max_batch = net.handle.query("max_batch") if self.async_ok else 0
@@ -35,6 +39,12 @@ class _Pipeline:
         vt = out["vt_prob"]
         bp = (1.0 - vt[:, 0]) if self.vt_thr else out["bp"]                   # trainer.py:611-621
         self.write("".join(scored_record(r, b, v) + "\n" for r, b, v in zip(batch.vcfrec, bp, vt)))
+        if self.stats is not None:
+            # sites whose scores sit within 1e-4 (the score tolerance of the parity gate) of a genotype threshold of the published
+            # pipeline (call_variants.sh:154-160): where a call could differ between two correct evaluations
+            d = threshold_distance(batch.vcfrec, vt, FormatOptions(**PIPELINE_OPTIONS))
+            self.stats["near_threshold"] = self.stats.get("near_threshold", 0) + int((d < NEAR_EPS).sum())
+            self.stats["sites"] = self.stats.get("sites", 0) + len(batch.vcfrec)
 
     def submit(self, batch):
         if self.async_ok and len(batch.vcfrec) <= self.max_batch:
@@ -54,14 +64,14 @@ class _Pipeline:
 
 def score_records(net, source: CandidateFile, write: Callable[[str], None], lo: int = 0, hi: Optional[int] = None,
                   sites_per_launch: int = 4096, reads_seed: int = 0, use_var_type_threshold: bool = False,
-                  log=None) -> int:
+                  log=None, stats=None) -> int:
     """Score records ``[lo, hi)`` of ``source`` with ``net`` (anything with ``forward_u8`` and ``config``) and hand
     each scored VCF line (with '\\n') to ``write``.  Returns the number of sites scored."""
     cfg = net.config
     hi = len(source) if hi is None else min(hi, len(source))
     done = 0
     t0 = time.perf_counter()
-    pipe = _Pipeline(net, write, use_var_type_threshold)
+    pipe = _Pipeline(net, write, use_var_type_threshold, stats)
     for b0 in range(lo, hi, sites_per_launch):
         recs = source.read(b0, min(b0 + sites_per_launch, hi))
         # the seed is tied to the ABSOLUTE record index, so shard boundaries never change a site's read subset
@@ -77,7 +87,7 @@ def score_records(net, source: CandidateFile, write: Callable[[str], None], lo: 
 
 def score_file_native(net, hdf_path: str, write: Callable[[str], None], lo: int, hi: int, sites_per_launch: int = 4096,
                       reads_seed: int = 0, use_var_type_threshold: bool = False, log=None,
-                      threads: int = 0) -> int:
+                      threads: int = 0, stats=None) -> int:
     """Same contract as ``score_records`` but fed by the native batched loader (dl4vc_amd/loader.py): chunk
     inflate and site assembly of batch k+1.. run in C++ threads while the GPU scores batch k."""
     import os
@@ -88,7 +98,7 @@ def score_file_native(net, hdf_path: str, write: Callable[[str], None], lo: int,
     t0 = time.perf_counter()
     with NativeLoader(hdf_path, cfg.reads, batch_sites=sites_per_launch, lo=lo, hi=hi, seed=reads_seed,
                       threads=threads) as nl:
-        pipe = _Pipeline(net, write, use_var_type_threshold)
+        pipe = _Pipeline(net, write, use_var_type_threshold, stats)
         for batch in nl:
             if not cfg.use_q:
                 batch.qual[:] = 0

@@ -221,6 +221,28 @@ def format_vcf_lines(lines: Sequence[str], options: FormatOptions = None) -> Lis
     return out
 
 
+def threshold_distance(vcfrecs: Sequence[str], vt_prob, options: FormatOptions = None) -> "np.ndarray":
+    """Per site, the distance of its scores to the nearest decision threshold ``format_vcf`` would hold them against: the call
+    threshold of the record's allele class on ``1 - NV``, that class's homozygous threshold on ``OV`` (format_vcf.py:107-126)
+    and, where the site passes, the two multi-allele thresholds on the call score (:158-196).  A score tolerance cannot by
+    itself guarantee identical genotype calls: a site closer to a threshold than the tolerance is where two correct
+    evaluations may disagree (hard part 4) -- this is the count the pipeline logs."""
+    import numpy as np
+    o = options or FormatOptions()
+    th = _Thresholds(o)
+    vt = np.asarray(vt_prob, np.float64)
+    out = np.empty(len(vcfrecs), np.float64)
+    for i, rec in enumerate(vcfrecs):
+        f = rec.split("\t")
+        thr, hz = th.pick(f[3], f[4])
+        call = 1.0 - vt[i, 0]
+        d = [abs(call - thr), abs(vt[i, 2] - hz)]
+        if call >= thr:
+            d += [abs(call - o.multiallele_second_threshold), abs(call - o.multiallele_homozygous_second_threshold)]
+        out[i] = min(d)
+    return out
+
+
 def format_vcf(input_file: str, output_file: str, options: FormatOptions = None) -> None:
     with open(input_file, "r") as f:
         lines = f.readlines()

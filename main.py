@@ -301,11 +301,15 @@ def main(argv=None) -> int:
     else:
         target = out_final + ".records"
     t_loop = time.time()
+    stats = {}
     n = run_shard(net, args.test_file, target, shard_i, shard_n, sites_per_launch=args.sites_per_launch,
                   reads_seed=args.reads_seed, use_var_type_threshold=args.use_var_type_threshold,
-                  holdout_chromosomes=holdout, site_limit=site_limit, log=lambda m: print(m, end="\r"))
+                  holdout_chromosomes=holdout, site_limit=site_limit, log=lambda m: print(m, end="\r"), stats=stats)
     t_loop = time.time() - t_loop
     net.close()
+    print("\n%d of %d sites lie within 1e-4 of a genotype threshold of the published pipeline (format_vcf flags of "
+          "call_variants.sh:154-160): only there could a call differ from another correct fp32 evaluation of the same scores"
+          % (stats.get("near_threshold", 0), stats.get("sites", 0)))
     print("\nscoring loop (HDF5 read + assembly + forward + VCF text): %d sites in %.2f s = %.0f sites/s" % (n, t_loop, n / max(t_loop, 1e-9)))
     if shard_n == 1:
         if args.sample_vcf:

@@ -128,6 +128,8 @@ def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor
     av = x.mean(dim=2, keepdim=True)
     feat = torch.cat((mx, av), dim=1).reshape(B, -1)
     if spec.bottleneck > 0:
+        if taps is not None:
+            taps["hwpre"] = torch.cat(hws, dim=1).detach().numpy().copy()     # (B, layers*H*R), layer-major, channel-major, read-minor
         feat = torch.cat((feat, F.relu(torch.cat(hws, dim=1))), dim=1)
     if taps is not None:
         taps["feature"] = feat.detach().numpy().copy()
@@ -140,13 +142,18 @@ def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor
 
     hidden = drop(feat, 0)                                           # conv2hidden.0            model.py:371-372
     for i, k in enumerate(fc_keys(sd)):                              # Linear, ReLU, Dropout    model.py:374
-        hidden = drop(F.relu(F.linear(hidden, sd[k + ".weight"], sd[k + ".bias"])), i + 1)
+        hidden = F.linear(hidden, sd[k + ".weight"], sd[k + ".bias"])
+        if taps is not None:
+            taps["fcpre%d" % i] = hidden.detach().numpy().copy()
+        hidden = drop(F.relu(hidden), i + 1)
     if taps is not None:
         taps["hidden"] = hidden.detach().numpy().copy()
 
     def head(name):
         return F.linear(hidden, sd[name + ".weight"], sd[name + ".bias"])
 
+    if taps is not None:
+        taps["covpre"] = head("fcHidden2Coverage").detach().numpy().copy()
     out = {"bin_logits": head("fcHidden2BinTarget"), "vt_logits": head("fcHidden2VT"),
            "af": torch.sigmoid(head("fcHidden2AF")), "cov": F.leaky_relu(head("fcHidden2Coverage")),
            "vb": head("fcHidden2VB"), "vr": head("fcHidden2VR")}

@@ -52,6 +52,10 @@ def test_main_py_inference(tmp_path, gpus):
            "--sites-per-launch", "16"] + MODEL_FLAGS
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    # every scoring process logs how many of its sites sit within 1e-4 of a genotype threshold (the knife-edge count)
+    import re
+    counts = [(int(a), int(b)) for a, b in re.findall(r"(\d+) of (\d+) sites lie within 1e-4 of a genotype threshold", r.stdout)]
+    assert len(counts) == gpus and sum(b for _, b in counts) == 24, r.stdout[-1500:]
     lines = open(str(tmp_path / "epoch1_model_test.vcf")).read().splitlines()
     assert lines[0].startswith("##fileformat") and lines[1].startswith("#CHROM")
     body = lines[2:]

@@ -222,31 +222,69 @@ def test_shape_errors_are_loud():
 
 
 def test_genotype_calls_identical_to_oracle():
-    """North-star gate: genotype strings after the format_vcf stage are identical whether the scores come from
-    the HIP path or from the oracle; also reports how many sites sit within 1e-4 of a decision threshold
-    (a score tolerance alone cannot guarantee identical calls on a knife edge -- SURVEY.md section 7)."""
+    """North-star gate: genotype calls after the format_vcf stage are identical whether the scores come from the HIP path --
+    fp32 Winograd (default), fp32 direct, bf16x3 -- or from the oracle, on 512 sites at production width.  The two score heads
+    are rescaled (as in smoke()) so that the probabilities are INTERIOR -- with seeded He-gain weights most softmaxes saturate
+    and a comparison of 0/1 values proves nothing -- and spread across the pipeline's thresholds (call 0.1 / 0.2, homozygous
+    0.75 / 0.8, call_variants.sh:154-160).  A score tolerance cannot by itself guarantee calls on a knife edge (SURVEY.md
+    section 7): the sites within 1e-4 of a threshold (dl4vc_amd.vcf.threshold_distance, the count main.py logs) are counted,
+    asserted to be few, written to gpurun_out/, and every OTHER site's call must be identical."""
+    import json
+    import os
+    import dataclasses
     from dl4vc_amd import vcf
+    from conftest import ROOT
+    n_sites = 512
     cfg = DanConfig(reads=64)
     sd = random_state_dict(cfg, seed=21)
-    batch = synth.make_sites(40, reads=64, seed=22)
-    net = DanNet(cfg).load_state_dict(sd)
-    got = net.forward_u8(*batch.arrays())
-    want = dan_forward_oracle(sd, cfg, *batch.arrays())
-    net.close()
+    batch = synth.make_sites(n_sites, reads=64, seed=22)
+    pre = dan_forward_oracle(sd, cfg, *batch.arrays(), taps=True)
+    hid = pre["hidden"].astype(np.float64)
+    want = {}
+    for head, key in (("fcHidden2VT", "vt_logits"), ("fcHidden2BinTarget", "bin_logits")):
+        g = np.float32(2.5 / max(1e-6, float(np.abs(pre[key]).max())))
+        sd[head + ".weight"] = sd[head + ".weight"] * g
+        sd[head + ".bias"] = sd[head + ".bias"] * g
+        want[key] = hid @ sd[head + ".weight"].astype(np.float64).T + sd[head + ".bias"].astype(np.float64)   # logits are linear in the head
+    e = np.exp(want["vt_logits"] - want["vt_logits"].max(axis=1, keepdims=True))
+    want["vt_prob"] = e / e.sum(axis=1, keepdims=True)
+    eb = np.exp(want["bin_logits"] - want["bin_logits"].max(axis=1, keepdims=True))
+    want["bp"] = 1.0 - (eb / eb.sum(axis=1, keepdims=True))[:, 0]
+    interior = int((want["vt_prob"].max(axis=1) < 0.99).sum())
+    assert interior >= n_sites // 2, "only %d of %d sites have interior probabilities" % (interior, n_sites)
     opts = vcf.FormatOptions(**vcf.PIPELINE_OPTIONS)
+    dist = vcf.threshold_distance(batch.vcfrec, want["vt_prob"], opts)
+    near = dist < 1e-4
 
     def calls(o):
+        """position -> genotype of every called site (format_vcf drops the others)"""
         lines = [vcf.scored_record(r, b, v) + "\n" for r, b, v in zip(batch.vcfrec, o["bp"], o["vt_prob"])]
         lines.sort(key=lambda l: (l.split("\t")[0], int(l.split("\t")[1])))
-        return [l.rstrip("\n").split("\t")[-1].split(":")[0] + "@" + l.split("\t")[1] for l in vcf.format_vcf_lines(lines, opts)]
+        return {l.split("\t")[1]: l.rstrip("\n").split("\t")[-1].split(":")[0] for l in vcf.format_vcf_lines(lines, opts)}
 
-    assert calls(got) == calls(want)
-    thr = np.array([0.1, 0.2])
-    call_score = 1.0 - want["vt_prob"][:, 0]
-    near = int((np.abs(call_score[:, None] - thr[None, :]).min(axis=1) < 1e-4).sum())
-    near += int((np.abs(want["vt_prob"][:, 2:3] - np.array([[0.75, 0.8]])).min(axis=1) < 1e-4).sum())
-    print("sites within 1e-4 of a genotype threshold: %d of %d" % (near, len(batch)))
-    assert np.abs(got["vt_prob"] - want["vt_prob"]).max() < SCORE_ATOL
+    ref_calls = calls(want)
+    pos = [r.split("\t")[1] for r in batch.vcfrec]
+    report = {"sites": n_sites, "interior_probability_sites": interior, "called_by_oracle": len(ref_calls),
+              "within_1e-4_of_a_threshold": int(near.sum()), "paths": {}}
+    for name, c in (("fp32_winograd", cfg), ("fp32_direct", dataclasses.replace(cfg, conv_algo=1)),
+                    ("bf16x3", dataclasses.replace(cfg, precision=1))):
+        net = DanNet(c).load_state_dict(sd)
+        got = net.forward_u8(*batch.arrays())
+        net.close()
+        err = float(np.abs(got["vt_prob"] - want["vt_prob"]).max())
+        assert err < SCORE_ATOL, (name, err)
+        mine = calls(got)
+        differ = [p for i, p in enumerate(pos) if mine.get(p) != ref_calls.get(p)]
+        off_edge = [p for i, p in enumerate(pos) if mine.get(p) != ref_calls.get(p) and not near[i]]
+        report["paths"][name] = {"max_abs_vt_prob_err": err, "calls_differing": len(differ), "differing_away_from_thresholds": len(off_edge)}
+        assert not off_edge, "%s: calls differ at sites that are not within 1e-4 of a threshold: %s" % (name, off_edge[:5])
+    print(json.dumps(report))
+    assert near.sum() <= max(2, n_sites // 100), "implausibly many knife-edge sites: %d" % near.sum()   # ~ 8 thresholds x 2e-4 wide
+    assert len(ref_calls) >= n_sites // 10 and len(set(ref_calls.values())) == 2      # both genotypes occur: the gate is not vacuous
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "genotype_gate.json"), "w") as f:
+        json.dump(report, f, indent=1)
 
 
 @pytest.mark.parametrize("length", [120, 208])
