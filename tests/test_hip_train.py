@@ -151,42 +151,94 @@ def test_production_width_step_against_oracle():
     tr.close()
 
 
-def _decision_margins(res, cfg, margin):
-    """Every discrete decision of one training step in the float64 oracle's taps whose operand lies within `margin` of the
+# margins (absolute) inside which a decision operand counts as "on a rounding edge": several times the distance at which the HIP
+# step's fp32 forward sits from the float64 oracle at that point of this network (measured, tests/diagnostics/strict_detail.py:
+# conv pre-activations 2e-6 .. 2e-5 with NO mask flip at a 2e-5 margin; the layer-7 output, which feeds the max, 1.6e-5)
+DECISION_MARGIN = {"conv": 2e-5, "bott": 5e-5, "hw": 1e-4, "fc": 1e-4, "cov": 1e-4, "max": 1e-4}
+
+
+def _decision_margins(res, cfg):
+    """Every discrete decision of one training step in the float64 oracle's taps whose operand lies within DECISION_MARGIN of the
     decision boundary: ReLU inputs (conv, bottleneck, concatenated highways, FC, the coverage head's leaky ReLU) and the final
     max over reads (top-1 minus top-2; exact ties -- identical all-padding rows -- follow torch's first-index rule on both sides
-    and are no rounding matter).  Returns a list of (kind, index...) offenders."""
+    and are no rounding matter).  Returns a list of (kind, i0, i1, value, margin) offenders."""
     bad = []
+    M = DECISION_MARGIN
     for l in range(1, cfg.layers + 1):
         for kind, key in (("conv", "tap:pre%d" % l), ("bott", "tap:hpre%d" % l)):
             a = res[key]
-            for c in np.unique(np.argwhere(np.abs(a) < margin)[:, 1]):
-                bad.append((kind, l, int(c), float(a[:, c][np.abs(a[:, c]) < margin].flat[0])))
+            for c in np.unique(np.argwhere(np.abs(a) < M[kind])[:, 1]):
+                bad.append((kind, l, int(c), float(a[:, c][np.abs(a[:, c]) < M[kind]].flat[0]), M[kind]))
     hw = res["tap:hwpre"]
     H, R = cfg.bottleneck, cfg.reads
-    for b, j in np.argwhere(np.abs(hw) < margin):
-        bad.append(("hw", int(j // (H * R)) + 1, int((j % (H * R)) // R), float(hw[b, j])))
+    for b, j in np.argwhere(np.abs(hw) < M["hw"]):
+        bad.append(("hw", int(j // (H * R)) + 1, int((j % (H * R)) // R), float(hw[b, j]), M["hw"]))
     for i in (0, 1):
         a = res["tap:fcpre%d" % i]
-        for b, j in np.argwhere(np.abs(a) < margin):
-            bad.append(("fc", i, int(j), float(a[b, j])))
-    if np.abs(res["tap:covpre"]).min() < margin:
-        bad.append(("cov", 0, 0, float(res["tap:covpre"].flat[np.abs(res["tap:covpre"]).argmin()])))
-    y = np.sort(res["tap:conv%d" % cfg.layers], axis=2)                    # (B,C,R,L) sorted over reads
+        for b, j in np.argwhere(np.abs(a) < M["fc"]):
+            bad.append(("fc", i, int(j), float(a[b, j]), M["fc"]))
+    if np.abs(res["tap:covpre"]).min() < M["cov"]:
+        bad.append(("cov", 0, 0, float(res["tap:covpre"].flat[np.abs(res["tap:covpre"]).argmin()]), M["cov"]))
+    yl = res["tap:conv%d" % cfg.layers]
+    y = np.sort(yl, axis=2)                                                # (B,C,R,L) sorted over reads
     gap = y[:, :, -1, :] - y[:, :, -2, :]
-    for b, c, p in np.argwhere((gap > 0) & (gap < margin)):
-        r = int(np.argmax(res["tap:conv%d" % cfg.layers][b, c, :, p]))
-        bad.append(("max", int(b), r, int(p)))
+    for b, c, p in np.argwhere((gap > 0) & (gap < M["max"])):
+        bad.append(("max", int(b), int(np.argmax(yl[b, c, :, p])), int(p), M["max"]))
     return bad
+
+
+def _move_decisions_off_their_edges(sd, cfg, planes, tg, ohp, masks, max_rounds=150):
+    """Nudges parameters until _decision_margins finds nothing, EARLIEST stage first so that a fix never disturbs a stage
+    already clean: conv layer l through its own bias (moves only what lies downstream of it), then the near-ties of the final
+    max through the last residual 1x1's weight row of the channel (scaled by 1 + 2e-3: changes only the last layer's output),
+    then each bottleneck, the highway, FC and coverage pre-activations through their own biases (nothing lies downstream of them
+    but the heads).  Returns (float64 oracle result of the final state, rounds)."""
+    import torch
+    order = {"conv": 0, "max": 1, "bott": 2, "hw": 3, "fc": 4, "cov": 5}
+    fc = sorted(k[:-7] for k in sd if k.startswith("conv2hidden.") and k.endswith(".weight"))
+    last_res = "residual_conv_layers.%d.weight" % (cfg.layers - cfg.residual_start)
+    prng = np.random.default_rng(99)
+    for it in range(max_rounds):
+        want = T.train_step_oracle(sd, cfg, planes, tg, ohp, dropout_masks=masks, dtype=torch.float64, taps=True)
+        bad = _decision_margins(want, cfg)
+        if not bad:
+            return want, it
+        first = min((order[b[0]], b[1] if b[0] in ("conv",) else 0) for b in bad)
+        seen = set()
+        for kind, i0, i1, v, m in bad:
+            if (order[kind], i0 if kind == "conv" else 0) != first:
+                continue
+            push = np.float32(m * prng.uniform(4.0, 30.0) * prng.choice((-1.0, 1.0)))    # (random: fixed steps can cycle between two
+            if kind == "conv":                                                             #  elements of one channel)
+                sd["conv1D_layers.%d.bias" % (i0 - 1)][i1] += push
+            elif kind == "max":                                      # (i0, i1, v) = (site, winning read, position); the channel is not
+                pass                                                 # in the tuple: handled below from the taps
+            elif kind == "bott":
+                sd["conv1D_bottleneck_layers.%d.bias" % (i0 - 1)][i1] += push
+            elif kind == "hw":
+                sd["conv1D_compression_layers.%d.bias" % (i0 - 1)][i1] += push
+            elif kind == "fc":
+                sd[fc[i0] + ".bias"][i1] += push
+            elif kind == "cov":
+                sd["fcHidden2Coverage.bias"][0] += push
+        if first[0] == order["max"]:
+            yl = want["tap:conv%d" % cfg.layers]
+            y = np.sort(yl, axis=2)
+            gap = y[:, :, -1, :] - y[:, :, -2, :]
+            for c in np.unique(np.argwhere((gap > 0) & (gap < DECISION_MARGIN["max"]))[:, 1]):
+                if c not in seen:
+                    seen.add(int(c))
+                    sd[last_res][c] *= np.float32(1.0 + prng.uniform(1e-3, 1e-2))
+    raise AssertionError("could not move every decision off its edge: %d left" % len(bad))
 
 
 def test_production_width_step_strict_bar_when_no_decision_sits_on_a_rounding_error():
     """The plain 1e-4 bar at production width.  fp32 and float64 evaluations of this network disagree on a
     gradient only where a discrete decision -- a ReLU mask, the read that wins the final max -- flips on a rounding error
     (profiles/r02_fuzz_train_160_structures.txt).  Here the inputs are first moved OFF every such edge: in the float64 oracle,
-    any ReLU input within 2e-5 of zero has its channel's bias nudged away from it, any near-tie of the final max has one quality
-    byte of the winning read changed, until no decision operand lies within 2e-5 of its boundary (fp32 summation noise at these
-    magnitudes is ~1e-6).  Then nothing can flip, and the hand-written step must meet 1e-4 of every gradient tensor's maximum
+    any ReLU input within DECISION_MARGIN (2e-5 .. 1e-4) of zero has its channel's bias nudged away from it, any such near-tie
+    of the final max has one quality byte of the winning read changed, until no decision operand lies that close to its
+    boundary (the fp32 forward sits 2e-6 .. 2e-5 from the float64 one).  Then nothing can flip, and the hand-written step must meet 1e-4 of every gradient tensor's maximum
     with no slack -- the bar the small-width reference fixtures are held to (trainer.py:213-217,425-439)."""
     import torch
     cfg = DanConfig(reads=6, fc_sizes=(64, 32))
@@ -196,6 +248,12 @@ def test_production_width_step_strict_bar_when_no_decision_sits_on_a_rounding_er
     B = 3
     batch = synth.make_sites(B, reads=cfg.reads, seed=24)
     planes = [a.copy() for a in batch.arrays()]
+    # every read random and every row non-empty: two reads that follow the reference are nearly identical over long stretches,
+    # and their outputs -- rivals in the final max -- then differ by less than any margin at hundreds of places
+    _r = np.random.default_rng(26)
+    planes[0] = _r.integers(1, 9, planes[0].shape).astype(np.uint8)
+    planes[1] = _r.integers(2, 42, planes[1].shape).astype(np.uint8)
+    planes[2] = _r.integers(1, 3, planes[2].shape).astype(np.uint8)
     rng = np.random.default_rng(25)
     hp = TrainHyper()
     tg = {"label": np.array([0, 2, 1]), "var_type": np.array([1, 0, 2]), "allele_freq": rng.random(B).astype(np.float32),
@@ -204,30 +262,7 @@ def test_production_width_step_strict_bar_when_no_decision_sits_on_a_rounding_er
     tg["weight"] = example_weights(tg["is_snp"], hp)
     masks = [(rng.random((B, w)) >= hp.dropout).astype(np.uint8) for w in (cfg.feature_width, 64, 32)]
     ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
-    MARGIN = 2e-5
-    fc = sorted(k[:-7] for k in sd if k.startswith("conv2hidden.") and k.endswith(".weight"))
-    for it in range(40):
-        want = T.train_step_oracle(sd, cfg, planes, tg, ohp, dropout_masks=masks, dtype=torch.float64, taps=True)
-        bad = _decision_margins(want, cfg, MARGIN)
-        if not bad:
-            break
-        for kind, i0, i1, v in bad:
-            push = np.float32(4 * MARGIN * (1 + it % 3)) * (1 if v >= 0 else -1)
-            if kind == "conv":
-                sd["conv1D_layers.%d.bias" % (i0 - 1)][i1] += push
-            elif kind == "bott":
-                sd["conv1D_bottleneck_layers.%d.bias" % (i0 - 1)][i1] += push
-            elif kind == "hw":
-                sd["conv1D_compression_layers.%d.bias" % (i0 - 1)][i1] += push
-            elif kind == "fc":
-                sd[fc[i0] + ".bias"][i1] += push
-            elif kind == "cov":
-                sd["fcHidden2Coverage.bias"][0] += push
-            else:                                                    # near-tie of the final max: one quality byte of the winner
-                b, r, p = i0, i1, int(v)
-                planes[1][b, r, p] = planes[1][b, r, p] + 1 if planes[1][b, r, p] < 250 else planes[1][b, r, p] - 1
-    else:
-        pytest.fail("could not move every decision off its edge: %d left" % len(bad))
+    want, it = _move_decisions_off_their_edges(sd, cfg, planes, tg, ohp, masks)
     print("decision operands moved off their edges in %d rounds" % it)
     tr = DanTrainer(cfg, hp, max_batch=4).load_state_dict(sd)
     out = tr.train_step(planes, tg, dropout_masks=masks)
