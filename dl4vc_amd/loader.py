@@ -19,7 +19,7 @@ from .synth import SiteBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdl4vc_loader.so")
 SYMBOLS = ("dl_open", "dl_num_records", "dl_num_sites", "dl_window", "dl_next", "dl_close", "dl_last_error",
-           "dl_select_rows", "dl_allele_masks")
+           "dl_select_rows", "dl_allele_masks", "pe_open", "pe_encode", "pe_close", "pe_last_error")
 _lib = None
 
 
@@ -40,6 +40,10 @@ def load_library() -> C.CDLL:
         lib.dl_last_error.argtypes = [vp]; lib.dl_last_error.restype = C.c_char_p
         lib.dl_select_rows.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         lib.dl_allele_masks.argtypes = [C.c_char_p, vp, vp, vp]
+        lib.pe_open.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(vp)]
+        lib.pe_encode.argtypes = [vp, C.POINTER(C.c_char_p), vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32]
+        lib.pe_close.argtypes = [vp]; lib.pe_close.restype = None
+        lib.pe_last_error.argtypes = [vp]; lib.pe_last_error.restype = C.c_char_p
         _lib = lib
     return _lib
 
@@ -105,3 +109,50 @@ class NativeLoader:
             self.close()
         except Exception:      # noqa: BLE001
             pass
+
+
+class PileupOptions(C.Structure):
+    """``pe_options`` of include/dl4vc_loader.h."""
+    _fields_ = [(n, C.c_int32) for n in ("window_size", "max_reads", "max_insert_length", "max_insert_length_variant", "min_base_quality")]
+
+
+class NativePileupEncoder:
+    """ctypes face of the native pileup encoder (``pe_*``, row N4): image planes of a run of locations, in order."""
+
+    def __init__(self, bam_path: str, fasta_path: str, window_size: int, max_reads: int, max_insert_length: int,
+                 max_insert_length_variant: int, min_base_quality: int = 0, bai_path: Optional[str] = None):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        self.window, self.max_reads = 2 * window_size + 1, max_reads
+        opt = PileupOptions(window_size, max_reads, max_insert_length, max_insert_length_variant, min_base_quality)
+        rc = self.lib.pe_open(bam_path.encode(), bai_path.encode() if bai_path else None, fasta_path.encode(), C.byref(opt), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise RuntimeError("pe_open failed: %s" % self.lib.pe_last_error(None).decode())
+
+    def encode(self, contigs, positions, threads: int = 1):
+        """-> (reads, qual, strand [n][max_reads][W] u8, ref [n][W] u8, num_reads [n] i32, status [n] i8)."""
+        n = len(positions)
+        names = (C.c_char_p * max(n, 1))(*[c.encode() for c in contigs])
+        pos = np.ascontiguousarray(positions, np.int32)
+        R, W = self.max_reads, self.window
+        reads, qual, strand = (np.zeros((n, R, W), np.uint8) for _ in range(3))
+        ref = np.zeros((n, W), np.uint8)
+        num = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        rc = self.lib.pe_encode(self._h, names, p(pos), n, p(reads), p(qual), p(strand), p(ref), p(num), p(status), int(threads))
+        if rc != 0:
+            raise RuntimeError("pe_encode failed: %s" % self.lib.pe_last_error(self._h).decode())
+        return reads, qual, strand, ref, num, status
+
+    def close(self):
+        if self._h is not None:
+            self.lib.pe_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

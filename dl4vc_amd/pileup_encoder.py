@@ -406,22 +406,51 @@ def encode_location(bam, fasta, loc: Location, opt: EncoderOptions, reader=None)
     return process_columns(cols(), loc.pos, opt)
 
 
-def encode_locations(bam_path: str, fasta_path: str, locations: Sequence[Location], opt: EncoderOptions) -> Tuple[np.ndarray, int]:
-    """Records for ``locations`` in input order and the number of locations that produced none."""
+def encode_locations(bam_path: str, fasta_path: str, locations: Sequence[Location], opt: EncoderOptions,
+                     native: Optional[bool] = None, threads: int = 1) -> Tuple[np.ndarray, int]:
+    """Records for ``locations`` in input order and the number of locations that produced none.
+
+    ``native`` (default: when libdl4vc_loader.so is built): the image planes come from the C++ encoder (``pe_encode``:
+    BGZF / BAM / CIGAR / image builder in ``threads`` worker threads); a location it declines (status 2: the cases
+    ``process_tracks`` hands to the column-by-column builder) is encoded here, so the records are the same bytes either
+    way (tests/test_pileup_native.py)."""
     from .bamio import BamFile, FastaFile, WindowReader
+    from . import loader
     dtype = record_dtype(opt.max_reads, 2 * opt.window_size + 1)
     out = np.zeros(len(locations), dtype)
     n = errors = 0
-    with BamFile(bam_path) as bam:
-        fasta = FastaFile(fasta_path)
-        reader = WindowReader(bam)
-        for loc in locations:
-            res = encode_location(bam, fasta, loc, opt, reader)
-            rec = finish_record(res, loc, opt, dtype) if res is not None else None
+    use_native = loader.available() if native is None else native
+    planes = None
+    if use_native and len(locations):
+        with loader.NativePileupEncoder(bam_path, fasta_path, opt.window_size, opt.max_reads, opt.max_insert_length,
+                                        opt.max_insert_length_variant, opt.min_base_quality) as enc:
+            planes = enc.encode([l.contig for l in locations], [l.pos for l in locations], threads)
+    bam = fasta = reader = None
+    try:
+        for i, loc in enumerate(locations):
+            status = int(planes[5][i]) if planes is not None else 2
+            if status == 1:
+                rec = np.zeros((), dtype)
+                rec["single_reads"], rec["q-scores"], rec["strand"] = planes[0][i], planes[1][i], planes[2][i]
+                rec["ref_bases"], rec["num_reads"] = planes[3][i], planes[4][i]
+                rec["name"] = loc.name.encode()[:dtype["name"].itemsize]
+                rec["label"] = loc.label
+                rec["vcfrec"] = loc.vcf_string.encode()[:dtype["vcfrec"].itemsize]
+            elif status == 0:
+                rec = None
+            else:
+                if bam is None:
+                    bam, fasta = BamFile(bam_path), FastaFile(fasta_path)
+                    reader = WindowReader(bam)
+                res = encode_location(bam, fasta, loc, opt, reader)
+                rec = finish_record(res, loc, opt, dtype) if res is not None else None
             if rec is None:
                 errors += 1
                 continue
             out[n] = rec
             n += 1
-        fasta.close()
+    finally:
+        if bam is not None:
+            bam.close()
+            fasta.close()
     return out[:n], errors

@@ -47,6 +47,33 @@ const char* dl_last_error(const dl_loader_t* l);       /* l may be NULL: error o
 int dl_select_rows(uint32_t seed, int32_t num_reads, int32_t stored_rows, int32_t max_reads, int32_t* rows_out);
 int dl_allele_masks(const char* vcfrec, const uint8_t* window /*[201]*/, uint8_t* ref_mask, uint8_t* var_mask);
 
+/* ---- native pileup encoder -------------------------------------------------------------
+ * Replaces the per-location work of the reference's converter, which it spreads over 80 pysam processes:
+ *   process_location                      tools/convert_bam_single_reads.py:846-1118   (pileup columns -> three image planes)
+ *   process_locations_chunk, image part   tools/convert_bam_single_reads.py:720-838    (crop / trim / centre / pad -> record)
+ *   samfile.pileup(...) / fetch           tools/convert_bam_single_reads.py:873-874    (BGZF, BAM records, BAI, CIGAR walk)
+ * pe_encode fills, for each location (contig name, 1-based VCF POS), the image fields of the converter's record
+ * (:694-698): single_reads / q-scores / strand [max_reads][2 w + 1], ref_bases [2 w + 1], num_reads; name / label / vcfrec are
+ * text the caller already has.  status: 1 = planes written, 0 = the location yields no record (no read over the candidate's
+ * column; the reference counts an error), 2 = the location needs the column-by-column form (reads sharing a name:sequence
+ * key, a reference skip, a base outside the token table, > 1000 columns, > 8000 reads, min_base_quality > 0): the Python
+ * module encodes those, so results are identical to dl4vc_amd/pileup_encoder.py for every location.  `threads` workers take
+ * contiguous runs of locations (locations sorted by position keep every alignment parsed once per run). */
+typedef struct pe_encoder pe_encoder_t;
+typedef struct pe_options {
+    int32_t window_size;                 /* --window-size (100) */
+    int32_t max_reads;                   /* --max-reads (call_variants.sh: 200) */
+    int32_t max_insert_length;           /* --max-insert-length (10) */
+    int32_t max_insert_length_variant;   /* --max-insert-length-variant (50) */
+    int32_t min_base_quality;            /* --min-base-quality (0) */
+} pe_options;
+int pe_open(const char* bam_path, const char* bai_path /* NULL: <bam>.bai, <stem>.bai, else a linear scan */, const char* fasta_path,
+            const pe_options* opt, pe_encoder_t** out);
+int pe_encode(pe_encoder_t* e, const char* const* contigs, const int32_t* positions, int64_t n, uint8_t* reads_out, uint8_t* qual_out,
+              uint8_t* strand_out, uint8_t* ref_out, int32_t* num_reads_out, int8_t* status_out, int32_t threads);
+void pe_close(pe_encoder_t* e);
+const char* pe_last_error(const pe_encoder_t* e);      /* e may be NULL: error of the last failed pe_open */
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,7 @@ def test_loader_header_symbols_exported():
         import __graft_entry__ as g
         g.build()
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dl4vc_loader.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(dl_[a-z_]+)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b((?:dl|pe)_[a-z_]+)\s*\(", text)))
     assert set(names) == set(loader.SYMBOLS)
     nl = loader.load_library()
     for n in names:
@@ -121,3 +121,11 @@ def test_flop_model_matches_survey():
     assert abs(production_config(100).flops_per_site() / 1e9 - 16.12) < 0.01
     assert abs(production_config(64).flops_per_site() / 1e9 - 10.35) < 0.01
     assert production_config(64).input_bytes_per_site() == 39195
+
+
+def test_pe_options_struct_matches_the_ctypes_mirror():
+    text = open(os.path.join(ROOT, "include", "dl4vc_loader.h")).read()
+    body = re.search(r"typedef struct pe_options \{(.*?)\} pe_options;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"int32_t\s+([a-z_]+)\s*;", body)
+    assert names == [f[0] for f in loader.PileupOptions._fields_]

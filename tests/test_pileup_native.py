@@ -1,0 +1,202 @@
+"""Native pileup encoder (libdl4vc_loader.so ``pe_*``) against the Python module it accelerates
+and against the fixture the reference's own helper functions pin (tests/golden/pileup_encoder.json.gz).  CPU only.
+
+The C++ side restates BGZF / BAM / BAI / CIGAR resolution / the read-by-read image builder / the crop-and-pad step; what it
+declines (status 2) is encoded by ``dl4vc_amd.pileup_encoder`` -- so ``encode_locations(native=True)`` must produce the very
+bytes of ``encode_locations(native=False)``, location by location."""
+import gzip
+import hashlib
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from dl4vc_amd import bamio, loader
+from dl4vc_amd.bamio import BamWriter, build_bai, CMATCH, CINS, CREF_SKIP, FREVERSE
+from dl4vc_amd import pileup_encoder as PE
+from oracle.gen_golden_pileup import simulate_reads
+
+pytestmark = pytest.mark.skipif(not loader.available(), reason="libdl4vc_loader.so not built")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "pileup_encoder.json.gz")
+IMAGE_FIELDS = ("single_reads", "q-scores", "strand", "ref_bases", "num_reads")
+
+
+def write_inputs(tmp, ref, reads, contig="ref", tag="x", line=70, index=True):
+    """FASTA + coordinate-sorted BAM (+ BAI) of simulated ``BamRecord``s."""
+    fa = str(tmp / ("%s.fa" % tag))
+    with open(fa, "w") as f:
+        f.write(">%s\n" % contig + "\n".join(ref[i:i + line] for i in range(0, len(ref), line)) + "\n")
+    bam = str(tmp / ("%s.bam" % tag))
+    with BamWriter(bam, [(contig, len(ref))]) as w:
+        for r in reads:
+            w.write(0, r.pos, r.name, r.flag, r.mapq, list(r.cigar), r.seq, r.qual.tolist())
+    if index:
+        build_bai(bam, bam + ".bai")
+    return bam, fa
+
+
+def both(bam, fa, locs, opt, threads=1):
+    py, e_py = PE.encode_locations(bam, fa, locs, opt, native=False)
+    nat, e_nat = PE.encode_locations(bam, fa, locs, opt, native=True, threads=threads)
+    return py, e_py, nat, e_nat
+
+
+def test_native_records_equal_python_on_simulated_pileups(tmp_path):
+    """The 40 simulated pileups of test_read_by_read_builder_equals_the_pinned_column_builder (insertions beyond both caps,
+    deletions, soft clips, both strands, duplicated names, soft-masked reference) through BAM files: identical bytes, and the
+    native path really took most of them (status 1), not the fallback."""
+    took = 0
+    for seed in range(40):
+        w = [100, 100, 30, 16][seed % 4]
+        opt = PE.EncoderOptions(window_size=w, max_reads=200, max_insert_length=[10, 3, 0][seed % 3], max_insert_length_variant=[50, 5, 0][seed % 3])
+        ref, center, reads = simulate_reads(100 + seed, w, [8, 40, 90, 300][seed % 4], duplicate_ids=(seed % 10 == 9))
+        bam, fa = write_inputs(tmp_path, ref, reads, tag="s%d" % seed, index=seed % 2 == 0)
+        locs = [PE.Location("ref", center, "ref:%d" % center, 2, "ref\t%d\t.\tA\tC" % center)]
+        py, e_py, nat, e_nat = both(bam, fa, locs, opt)
+        assert e_py == e_nat and py.tobytes() == nat.tobytes(), seed
+        with loader.NativePileupEncoder(bam, fa, w, 200, opt.max_insert_length, opt.max_insert_length_variant) as enc:
+            st = enc.encode(["ref"], [center])[5]
+        took += int(st[0] == 1)
+    assert took >= 30
+
+
+def test_native_planes_match_the_reference_pinned_fixture(tmp_path):
+    """The fixture's cases were made from ``simulate_reads`` (seed, window, reads): the same reads through a BAM file and the
+    native encoder give the record planes the REFERENCE's add_bases / handle_ended / resize / centre / trim functions produced
+    (sha256 in tests/golden/pileup_encoder.json.gz) wherever the native path takes the location itself."""
+    with gzip.open(GOLDEN, "rt") as f:
+        cases = json.load(f)["cases"]
+    specs = [(1, 20, 12, 200, 10, 50, False), (2, 100, 40, 200, 10, 50, False), (3, 100, 90, 200, 10, 50, True),
+             (4, 100, 260, 200, 10, 50, False), (5, 30, 25, 10, 3, 5, False), (6, 100, 30, 200, 0, 0, False),
+             (7, 100, 60, 50, 10, 50, True), (8, 16, 6, 200, 10, 50, False), (9, 100, 1300, 1000, 10, 50, False)]
+    checked = 0
+    for (seed, w, n_reads, max_reads, mil, milv, dup), case in zip(specs, cases):
+        assert case["window_size"] == w and case["max_reads"] == max_reads
+        ref, center, reads = simulate_reads(seed, w, n_reads, 600, dup)
+        assert center == case["center_position"]
+        bam, fa = write_inputs(tmp_path, ref, reads, tag="g%d" % seed)
+        with loader.NativePileupEncoder(bam, fa, w, max_reads, mil, milv) as enc:
+            rd, ql, st, rf, num, status = enc.encode(["ref"], [center])
+        want = case["want"]
+        if status[0] == 2:
+            continue                                                 # (duplicated name:sequence keys: the column path's case)
+        if want is None or want["record"] is None:
+            assert status[0] == 0
+            continue
+        assert status[0] == 1
+        for got, key in ((rd[0], "single_reads"), (ql[0], "q-scores"), (st[0], "strand"), (rf[0], "ref_bases")):
+            assert list(got.shape) == want["record"][key]["shape"]
+            assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == want["record"][key]["sha256"], (seed, key)
+        assert int(num[0]) == want["record"]["num_reads"]
+        checked += 1
+    assert checked >= 6
+
+
+def _big_case(tmp_path, n_reads=900, length=6000, seed=5):
+    rng = np.random.default_rng(seed)
+    ref = "".join(rng.choice(list("ACGT"), length))
+    recs = []
+    for i in range(n_reads):
+        s = int(rng.integers(0, length - 160))
+        n = int(rng.integers(80, 151))
+        seq, cigar, p = [], [], s
+        left = n
+        while left > 0:
+            m = int(min(left, rng.integers(10, 70)))
+            block = list(ref[p:p + m])
+            for j in range(m):
+                if rng.random() < 0.02:
+                    block[j] = str(rng.choice(list("ACGTN")))
+            cigar.append((CMATCH, m)); seq += block; p += m; left -= m
+            if left <= 0:
+                break
+            u = rng.random()
+            if u < 0.15:
+                k = int(rng.integers(1, 15)); cigar.append((CINS, k)); seq += list(rng.choice(list("ACGT"), k)); left -= k
+            elif u < 0.3:
+                k = int(rng.integers(1, 9)); cigar.append((bamio.CDEL, k)); p += k
+        while cigar[-1][0] != CMATCH:
+            op, k = cigar.pop()
+            if op == CINS:
+                del seq[-k:]
+        flag = (FREVERSE if rng.random() < 0.5 else 0) | (bamio.FDUP if rng.random() < 0.03 else 0)
+        recs.append(bamio.BamRecord(0, s, 40, flag, "q%d" % i, tuple(cigar), "".join(seq), rng.integers(2, 42, len(seq)).astype(np.uint8)))
+    recs.sort(key=lambda r: r.pos)
+    bam, fa = write_inputs(tmp_path, ref, recs, contig="chr20", tag="big")
+    return bam, fa, ref
+
+
+def test_runs_of_locations_threads_and_unsorted_queries(tmp_path):
+    """A 6-kbp contig at ~20x with insertions, deletions and duplicate-flagged reads; 150 locations, in
+    position order and shuffled (the window reader then restarts through the index), 1 and 3 worker threads, a location past
+    the data and one on a missing contig: identical records, identical error counts."""
+    bam, fa, ref = _big_case(tmp_path)
+    rng = np.random.default_rng(9)
+    pos = np.sort(rng.integers(150, 5850, 150))
+    locs = [PE.Location("chr20", int(p), "chr20:%d" % p, 2, "chr20\t%d\t.\t%s\tG" % (p, ref[p - 1])) for p in pos]
+    locs.append(PE.Location("chrX", 100, "chrX:100", 2, "chrX\t100\t.\tA\tC"))
+    opt = PE.EncoderOptions(window_size=100, max_reads=200)
+    py, e_py, nat, e_nat = both(bam, fa, locs, opt)
+    assert e_py == e_nat and len(py) == len(nat) and py.tobytes() == nat.tobytes()
+    assert len(py) >= 140
+    nat3, e3 = PE.encode_locations(bam, fa, locs, opt, native=True, threads=3)
+    assert e3 == e_py and nat3.tobytes() == py.tobytes()
+    order = rng.permutation(len(locs))
+    shuffled = [locs[i] for i in order]
+    py_s, e_s = PE.encode_locations(bam, fa, shuffled, opt, native=False)
+    nat_s, e_ns = PE.encode_locations(bam, fa, shuffled, opt, native=True, threads=2)
+    assert e_s == e_ns and py_s.tobytes() == nat_s.tobytes()
+    with loader.NativePileupEncoder(bam, fa, 100, 200, 10, 50) as enc:
+        status = enc.encode([l.contig for l in locs], [l.pos for l in locs], 2)[5]
+    assert (status == 1).sum() >= 140 and status[-1] == 0
+
+
+def test_what_the_read_by_read_form_declines_comes_back_as_status_2(tmp_path):
+    """A reference skip (the reference's tables have no entry for '>' / '<': its converter raises, and so does the Python column
+    path), two reads sharing name AND sequence, --min-base-quality: the native encoder hands them back (status 2), never guesses."""
+    ref = "ACGT" * 100
+    mk = lambda pos, name, cigar, seq: bamio.BamRecord(0, pos, 30, 0, name, tuple(cigar), seq, np.full(len(seq), 30, np.uint8))   # noqa: E731
+    skip = [mk(150, "s", [(CMATCH, 20), (CREF_SKIP, 30), (CMATCH, 20)], ref[150:170] + ref[200:220])]
+    bam, fa = write_inputs(tmp_path, ref, skip, tag="skip")
+    with loader.NativePileupEncoder(bam, fa, 16, 50, 10, 50) as enc:
+        assert enc.encode(["ref"], [160])[5][0] == 2
+    with pytest.raises(KeyError):
+        PE.encode_locations(bam, fa, [PE.Location("ref", 160, "ref:160", 2, "ref\t160\t.\tA\tC")], PE.EncoderOptions(window_size=16, max_reads=50))
+    twins = [mk(140, "t", [(CMATCH, 40)], ref[140:180]), mk(149, "t", [(CMATCH, 40)], ref[140:180]), mk(150, "u", [(CMATCH, 40)], ref[150:190])]
+    bam, fa = write_inputs(tmp_path, ref, twins, tag="twins")
+    with loader.NativePileupEncoder(bam, fa, 16, 50, 10, 50) as enc:
+        assert enc.encode(["ref"], [160])[5][0] == 2
+    opt = PE.EncoderOptions(window_size=16, max_reads=50)
+    loc = [PE.Location("ref", 160, "ref:160", 2, "ref\t160\t.\tA\tC")]
+    py, e_py, nat, e_nat = both(bam, fa, loc, opt)
+    assert e_py == e_nat and py.tobytes() == nat.tobytes() and len(py) == 1
+    with loader.NativePileupEncoder(bam, fa, 16, 50, 10, 50, min_base_quality=5) as enc:
+        assert enc.encode(["ref"], [160])[5][0] == 2
+
+
+def test_native_is_much_faster_than_the_python_path(tmp_path):
+    """>= 20x per core.  (Informational print of the per-location cost; the assertion is a conservative 8x so
+    that a loaded CI box does not flake.)"""
+    bam, fa, ref = _big_case(tmp_path, n_reads=2400, length=12000, seed=8)       # ~30x
+    pos = np.arange(300, 11700, 19)
+    locs = [PE.Location("chr20", int(p), "chr20:%d" % p, 2, "chr20\t%d\t.\t%s\tG" % (p, ref[p - 1])) for p in pos]
+    opt = PE.EncoderOptions(window_size=100, max_reads=200)
+    with loader.NativePileupEncoder(bam, fa, 100, 200, 10, 50) as enc:
+        t0 = time.perf_counter()
+        status = enc.encode([l.contig for l in locs], [l.pos for l in locs], 1)[5]
+        t_nat = time.perf_counter() - t0
+    fast = [l for l, s in zip(locs, status) if s == 1][:120]
+    t0 = time.perf_counter()
+    PE.encode_locations(bam, fa, fast, opt, native=False)
+    t_py = (time.perf_counter() - t0) / len(fast)
+    per_nat = t_nat / len(locs)
+    print("native %.3f ms per location (1 thread, %d locations, %d on the native path), python %.2f ms: %.0fx"
+          % (per_nat * 1e3, len(locs), int((status == 1).sum()), t_py * 1e3, t_py / per_nat))
+    assert t_py / per_nat > 8
+
+
+def test_open_errors_are_reported():
+    with pytest.raises(RuntimeError, match="cannot open|not a BAM"):
+        loader.NativePileupEncoder("/nonexistent.bam", "/nonexistent.fa", 100, 200, 10, 50)

@@ -88,7 +88,12 @@ def main(argv=None):
     print("Processing %d locations with %d process" % (n_loc, procs))
     print("Splitting locations into ~%d chunks [%d each] to save memory..." % (math.ceil(max(n_loc - start, 0) / step), step))
     pool = None
-    if procs > 1 and n_loc - start > 4 * procs:
+    from dl4vc_amd import loader
+    native = loader.available() and not os.environ.get("DL4VC_PILEUP_PYTHON")
+    if native:
+        # the native encoder (libdl4vc_loader.so, pe_*): --num-processes becomes worker THREADS over contiguous runs of locations
+        print("native pileup encoder: %d thread(s)" % procs)
+    if not native and procs > 1 and n_loc - start > 4 * procs:
         import multiprocessing as mp
         pool = mp.get_context("spawn").Pool(procs)
     total_errors, written, created = 0, 0, append
@@ -103,7 +108,7 @@ def main(argv=None):
                 recs = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0)
                 errors = sum(p[1] for p in parts)
             else:
-                recs, errors = encode_locations(args.input, args.fasta_input, chunk, opt)
+                recs, errors = encode_locations(args.input, args.fasta_input, chunk, opt, native=native, threads=procs)
             total_errors += errors
             if not created:
                 hdf5io.write_candidates(args.output, recs, chunk=8)
