@@ -124,6 +124,7 @@ def test_flop_model_matches_survey():
 
 
 def test_pe_options_struct_matches_the_ctypes_mirror():
+    from dl4vc_amd import loader
     text = open(os.path.join(ROOT, "include", "dl4vc_loader.h")).read()
     body = re.search(r"typedef struct pe_options \{(.*?)\} pe_options;", text, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
