@@ -363,6 +363,55 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
         bias[n] = a.bias1 ? *(const v4f*)(a.bias1 + chb[n]) : splat(0.f);
     }
     const long long per_site = (long long)a.R * L;
+    // The addends of ALL eight (m, n) cells are requested before the first is used, tensor by tensor: one memory round trip per
+    // tensor and workgroup instead of one per cell (the cells' loads sat behind each other's uses, eight exposed round trips
+    // in a workgroup that lives for about twenty).  Same operations in the same order per element.
+    auto cell_off = [&](int m, int n) { return (size_t)(base + m * 16 + pos) * CPAD + chb[n]; };
+    auto fetch = [&](const float* src, v4f (&dst)[TP_MT][NT]) {
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dst[m][n] = (m * 16 + pos < n_here) ? *(const v4f*)(src + cell_off(m, n)) : splat(0.f);
+    };
+    v4f aux[TP_MT][NT];
+    const bool own_aux = a.stats && a.stat_aux;
+    if (own_aux) fetch(a.stat_aux, aux);
+#pragma unroll
+    for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] += bias[n];
+    if (a.add1) {
+        v4f t[TP_MT][NT];
+        fetch(a.add1, t);
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] += t[m][n];
+    }
+    if (a.add2) {
+        v4f t[TP_MT][NT];
+        fetch(a.add2, t);
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] += t[m][n];
+    }
+    if (a.addb) {
+        v4f t[TP_MT][NT];
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m) {
+            const long long q = base + m * 16 + pos;
+            const long long site = q / per_site;
+            const int p = (int)(q % L);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                t[m][n] = (m * 16 + pos < n_here) ? *(const v4f*)(a.addb + ((size_t)site * L + p) * CPAD + chb[n]) : splat(0.f);
+        }
+#pragma unroll
+        for (int m = 0; m < TP_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] += t[m][n];
+    }
 #pragma unroll
     for (int m = 0; m < TP_MT; ++m) {
         const int pl = m * 16 + pos;
@@ -371,26 +420,17 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
         for (int n = 0; n < NT; ++n) {
             v4f v = splat(0.f);
             if (live) {
-                const long long q = base + pl;
-                const size_t o = (size_t)q * CPAD + chb[n];
-                v = acc[m][n] + bias[n];
-                if (a.add1) v += *(const v4f*)(a.add1 + o);
-                if (a.add2) v += *(const v4f*)(a.add2 + o);
-                if (a.addb) {
-                    const long long site = q / per_site;
-                    const int p = (int)(q % L);
-                    v += *(const v4f*)(a.addb + ((size_t)site * L + p) * CPAD + chb[n]);
-                }
+                v = acc[m][n];
                 if (a.relu_out) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
                 if (a.stats) {
-                    const v4f x = a.stat_aux ? *(const v4f*)(a.stat_aux + o) : v;
+                    const v4f x = own_aux ? aux[m][n] : v;
                     s0[n] += v;
                     s1v[n] += v * x;
                 }
-                if (a.out1) *(v4f*)(a.out1 + o) = v;
+                if (a.out1) *(v4f*)(a.out1 + cell_off(m, n)) = v;
             }
             acc[m][n] = v;
         }
@@ -635,6 +675,22 @@ __device__ __forceinline__ T ordered_sum(int n, F load) {
     return sum;
 }
 
+// two sums over the same index range, their loads in flight together (each sum in index order)
+template <typename T, typename F0, typename F1>
+__device__ __forceinline__ void ordered_sum2(int n, F0 load0, F1 load1, T& out0, T& out1) {
+    T s0 = (T)0, s1 = (T)0;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+        T v[16], u[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = load0(i + j); u[j] = load1(i + j); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s0 += v[j]; s1 += u[j]; }
+    }
+    for (; i < n; ++i) { s0 += load0(i); s1 += load1(i); }
+    out0 = s0; out1 = s1;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
                                                            int wgs, int taps, int OP, int CP, int n_out, int n_in,
                                                            const int* __restrict__ cmap, float* g_w, float* g_b) {
@@ -683,8 +739,8 @@ __global__ __launch_bounds__(CPAD) void bn_forward_finalize_kernel(const double*
     const int ch = threadIdx.x;
     float scale = 0.f, shift = 0.f;
     if (ch < channels) {
-        const double s0 = ordered_sum<double>(nb, [&](int b) { return bp[(size_t)b * 2 * CPAD + ch]; });
-        const double s1 = ordered_sum<double>(nb, [&](int b) { return bp[(size_t)b * 2 * CPAD + CPAD + ch]; });
+        double s0, s1;
+        ordered_sum2<double>(nb, [&](int b) { return bp[(size_t)b * 2 * CPAD + ch]; }, [&](int b) { return bp[(size_t)b * 2 * CPAD + CPAD + ch]; }, s0, s1);
         const double mean = s0 / n_pos;
         double var = s1 / n_pos - mean * mean;                  // biased variance normalises (nn.BatchNorm2d, training)
         if (var < 0.0) var = 0.0;
@@ -717,8 +773,8 @@ __global__ __launch_bounds__(CPAD) void bn_backward_coef_kernel(const double* __
     float A = 0.f, B = 0.f, C = 0.f;
     if (ch < channels) {
         if (use_bn) {
-            const double s0 = ordered_sum<double>(nb, [&](int b) { return bp[(size_t)b * 2 * CPAD + ch]; });
-            const double s1 = ordered_sum<double>(nb, [&](int b) { return bp[(size_t)b * 2 * CPAD + CPAD + ch]; });
+            double s0, s1;
+            ordered_sum2<double>(nb, [&](int b) { return bp[(size_t)b * 2 * CPAD + ch]; }, [&](int b) { return bp[(size_t)b * 2 * CPAD + CPAD + ch]; }, s0, s1);
             const double mu = save_mean[ch], r = save_invstd[ch], g = gamma[ch];
             const double dbeta = s0, dgamma = (s1 - mu * s0) * r;
             g_gamma[ch] = (float)dgamma;

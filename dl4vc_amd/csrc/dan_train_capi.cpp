@@ -77,6 +77,7 @@ struct dan_trainer {
     float *d_coef_f = nullptr, *d_coef_b = nullptr, *d_smean = nullptr, *d_sinv = nullptr;
     // inputs / targets
     uint8_t* d_in = nullptr;
+    uint8_t* h_stage = nullptr;                  // pinned mirror of d_in | d_tg8 | d_tgf: a step's inputs go up in three asynchronous copies
     uint8_t* d_tg8 = nullptr;
     float* d_tgf = nullptr;
     uint8_t* d_mask[3] = {nullptr, nullptr, nullptr};
@@ -358,6 +359,7 @@ int dan_train_finalize(dan_trainer_t* t) {
     // ---- inputs, targets, masks
     const size_t in_site = (size_t)3 * R * L + 3 * L;
     if ((rc = talloc(t, &t->d_in, (size_t)B * in_site)) || (rc = talloc(t, &t->d_tg8, (size_t)B * 4)) || (rc = talloc(t, &t->d_tgf, (size_t)B * 3))) return rc;
+    HIPT(t, hipHostMalloc((void**)&t->h_stage, (size_t)B * (in_site + 4 + 3 * sizeof(float)), hipHostMallocDefault));
     if ((rc = talloc(t, &t->d_mask[0], (size_t)B * t->F)) || (rc = talloc(t, &t->d_mask[1], (size_t)B * t->n0)) || (rc = talloc(t, &t->d_mask[2], (size_t)B * t->n1))) return rc;
     // ---- activations
     const size_t rowf = (size_t)L * CPAD;
@@ -401,6 +403,7 @@ void dan_train_destroy(dan_trainer_t* t) {
     (void)hipDeviceSynchronize();
     for (void* p : t->allocs) (void)hipFree(p);
     if (t->ev_tail) (void)hipEventDestroy(t->ev_tail);
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
     delete t;
 }
 
@@ -479,21 +482,20 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
     const double n_pos = (double)n_rows * L;
     t->last_B = B;
     // ---- inputs
-    {
-        uint8_t* d = t->d_in;
-        HIPT(t, hipMemcpy(d, reads, B * rl, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(d + B * rl, qual, B * rl, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(d + 2 * B * rl, strand, B * rl, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(d + 3 * B * rl, ref, (size_t)B * L, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(d + 3 * B * rl + (size_t)B * L, ref_mask, (size_t)B * L, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(d + 3 * B * rl + (size_t)2 * B * L, var_mask, (size_t)B * L, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tg8, tg->label, B, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tg8 + B, tg->var_type, B, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tg8 + 2 * B, tg->var_base_enum, B, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tg8 + 3 * B, tg->var_ref_enum, B, hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tgf, tg->allele_freq, B * sizeof(float), hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tgf + B, tg->coverage, B * sizeof(float), hipMemcpyHostToDevice));
-        HIPT(t, hipMemcpy(t->d_tgf + 2 * B, tg->weight, B * sizeof(float), hipMemcpyHostToDevice));
+    {   // the seventeen caller arrays are gathered in the pinned mirror (same layout as on the device) and go up in three
+        // stream-ordered copies; the mirror is free again: the previous step's copies completed before its dan_train_backward_end returned
+        uint8_t* h = t->h_stage;
+        size_t o = 0;
+        auto stage = [&](const void* src, size_t n) { memcpy(h + o, src, n); o += n; };
+        stage(reads, B * rl); stage(qual, B * rl); stage(strand, B * rl);
+        stage(ref, (size_t)B * L); stage(ref_mask, (size_t)B * L); stage(var_mask, (size_t)B * L);
+        const size_t n_in = o;
+        stage(tg->label, B); stage(tg->var_type, B); stage(tg->var_base_enum, B); stage(tg->var_ref_enum, B);
+        const size_t n_tg8 = o - n_in;
+        stage(tg->allele_freq, B * sizeof(float)); stage(tg->coverage, B * sizeof(float)); stage(tg->weight, B * sizeof(float));
+        HIPT(t, hipMemcpyAsync(t->d_in, h, n_in, hipMemcpyHostToDevice, s));
+        HIPT(t, hipMemcpyAsync(t->d_tg8, h + n_in, n_tg8, hipMemcpyHostToDevice, s));
+        HIPT(t, hipMemcpyAsync(t->d_tgf, h + n_in + n_tg8, o - n_in - n_tg8, hipMemcpyHostToDevice, s));
     }
     const bool drop = hp.dropout > 0.f;
     const float dscale = drop ? 1.f / (1.f - hp.dropout) : 1.f;
