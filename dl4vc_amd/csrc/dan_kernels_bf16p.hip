@@ -50,7 +50,22 @@ __device__ unsigned long long* g_pstamps;
 #endif
 
 __device__ __forceinline__ v16f mfma32(bf8 a, bf8 b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+// ReLU as ONE integer maximum on the bit pattern (negative floats, -0 included, are negative integers): through fmed3 / fmaxf
+// hipcc emits a canonicalising v_max_f32 v, v first -- two vector instructions per value in an epilogue bounded by vector issue.
+// (Not inline assembly: the hazard recogniser does not see an asm operand, and a ReLU right behind an MFMA read stale registers.)
+__device__ __forceinline__ float relu1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// v * s + t on register pairs (v_pk_fma_f32: half the issue slots of sixteen v_fma_f32; left to itself hipcc packs about a third)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void scale_shift16(v16f& v, const v16f& s, const v16f& t) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const v2f r = __builtin_elementwise_fma((v2f){v[i], v[i + 1]}, (v2f){s[i], s[i + 1]}, (v2f){t[i], t[i + 1]});
+        v[i] = r[0]; v[i + 1] = r[1];
+    }
+}
 
 __device__ __forceinline__ bf8 lds_read(const char* lds, unsigned addr) { return *(const bf8*)(lds + addr); }
 __device__ __forceinline__ void lds_write(char* lds, unsigned addr, bf8 v) { *(bf8*)(lds + addr) = v; }
@@ -399,7 +414,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                     const int p = pbase + 32 * m + n;
                     v16f v = acc[m];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]) * sc[i] + sh[i];
+                    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
+                    scale_shift16(v, sc, sh);
                     if (pbase + 32 * m + 32 > L) {               // (uniform) the tile reaches past the window
 #pragma unroll
                         for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
@@ -743,7 +759,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentq_kernel(Segmen
                     const int p = pb + 32 * m + n;
                     v16f v = acc[m];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]) * sc[i] + sh[i];
+                    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
+                    scale_shift16(v, sc, sh);
                     if (pb + 32 * m + 32 > L) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
