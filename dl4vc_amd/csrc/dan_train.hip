@@ -76,49 +76,57 @@ __device__ __forceinline__ v4f load_transform(v4f s1, v4f s2, const float* coef,
 // T1: one layer-shaped step on the LDS-resident read
 // ------------------------------------------------------------------------------------------------
 constexpr int TR_LDS_ROWS = (WINO_ROWS_READ > LDS_ROWS ? WINO_ROWS_READ : LDS_ROWS);      // Winograd tiles past the window read a few rows on
-__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowArgs a) {
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowArgs a, int n_rows) {
     __shared__ __attribute__((aligned(16))) float xs[TR_LDS_ROWS * LDS_S];
     __shared__ float sred[2][2][CPAD];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row = blockIdx.x;
-    const int site = row / a.R;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int L = a.L;
-    if (a.mode == 0) {
-        // encode writes 48 of a row's 128 channels and layer 1 reads only those: clear the whole image once
-        for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
-        __syncthreads();
-        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
-        encode_rows(xs, LDS_S, HALO, 0, L, e, (size_t)row, site, L, tid);
-    } else {
-        const int vpr = a.s1_stride >> 2;                       // 16-byte vectors per position
-        const int n4 = L * vpr;
-        const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * a.s1_stride);
-        const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)row * L * a.s1_stride) : nullptr;
-        const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
-        // the whole read (and its second tensor / pool image) in flight at once, then transform + store: a loop of dependent
-        // load -> LDS store round trips leaves one CU streaming at a few loads per latency
-        // (rows loaded from a 128-channel tensor cover every column the GEMMs read: only the rows the read does not cover --
-        // halo rows and rows >= L -- are cleared, disjoint from the rows stored below, so no barrier in between)
-        if (vpr < CPAD / 4) {                                    // (a narrower tensor: clear everything first)
-            for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
-            __syncthreads();
-        } else {
-            for (int i = tid; i < (TR_LDS_ROWS - L) * (LDS_S / 4); i += SEG_THREADS) {
-                const int rr = i / (LDS_S / 4), c4 = i - rr * (LDS_S / 4);
-                const int zr = rr < HALO ? rr : rr + L;
-                *(v4f*)(xs + zr * LDS_S + c4 * 4) = splat(0.f);
-            }
-        }
-        constexpr int NP = (MPOS * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;     // 13
-        v4f r1[NP], r2[NP], r3[NP];
+    // PERSISTENT: workgroup b walks reads b, b + grid, ... (one workgroup per CU: the image is 119 KB) -- no workgroup launch and
+    // no image clear per read, and the NEXT read's tensors (13 x 16 bytes per thread each) are requested behind this read's GEMM:
+    // their round trip passes under the epilogue's stores and barriers instead of in front of idle matrix pipes.  (Requested
+    // AHEAD of the GEMM they cost 148 spilled registers beside the Winograd accumulators.)  The image is cleared ONCE: a read's stores cover rows [HALO, HALO + L) x all 128 channels (encode: its 45 of the 48 that
+    // layer 1 reads), the halo rows and the rows past the window are never written again.
+    for (int i = tid0; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+    __syncthreads();
+    constexpr int NP = (MPOS * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;     // 13
+    const int vpr = a.s1_stride >> 2;                           // 16-byte vectors per position
+    const int n4 = L * vpr;
+    v4f r1[NP], r2[NP];
+    auto request = [&](int rw, int tid) {                        // a read's first and second tensor
+        const v4f* s1 = (const v4f*)(a.src1 + (size_t)rw * L * a.s1_stride);
+        const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)rw * L * a.s1_stride) : nullptr;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int i = tid + k * SEG_THREADS;
             const bool ok = i < n4;
             r1[k] = ok ? s1[i] : splat(0.f);
             r2[k] = (ok && s2) ? s2[i] : splat(0.f);
-            r3[k] = (ok && pl) ? pl[i] : splat(0.f);
+        }
+    };
+    if (a.mode != 0 && (int)blockIdx.x < n_rows) request(blockIdx.x, tid0);
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    // (an opaque copy of the thread index per read: hipcc otherwise forms every per-lane address of the body ahead of the loop
+    // and keeps them -- spilled -- through the GEMMs)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int site = row / a.R;
+    const int next = row + (int)gridDim.x;
+    if (a.mode == 0) {
+        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
+        encode_rows(xs, LDS_S, HALO, 0, L, e, (size_t)row, site, L, tid);
+    } else {
+        const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
+        if (vpr < CPAD / 4) {                                    // (a narrower tensor: the columns it does not cover must read zero)
+            for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+            __syncthreads();
+        }
+        v4f r3[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            r3[k] = (i < n4 && pl) ? pl[i] : splat(0.f);
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -149,6 +157,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc4[m][k] = splat(0.f);
         conv_gemm_wino(acc4, xs + (HALO + wP0 - 2) * LDS_S + kk * 4, w_w, pre_w);
+        // the next read's tensors travel under this read's epilogue (always redefined -- the last read re-requests itself --
+        // or the old values would count as live through the GEMM: 104 registers)
+        request(min(next, n_rows - 1), tid);
         const v4f bias = a.bias1 ? *(const v4f*)(a.bias1 + chw) : splat(0.f);
         v4f s0 = splat(0.f), s1 = splat(0.f);
 #pragma unroll
@@ -186,7 +197,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
                 }
             }
         }
-        return;                                                  // (no bottleneck stage rides on the 3-tap launches)
+        __syncthreads();                                         // every wave has finished reading the image
+        continue;                                                // (no bottleneck stage rides on the 3-tap launches)
     }
     const int cq = wave & 3, ph = wave >> 2;
     const int m_base = ph * MTW, cnt = ph ? MT - MTW : MTW;
@@ -202,12 +214,22 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = splat(0.f);
         conv_gemm(acc, xs, w, first, a.kg, a.taps, a.dil, lane, m_base, cnt);
+        if (a.mode != 0) request(min(next, n_rows - 1), tid);
+        else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { r1[k] = splat(0.f); r2[k] = splat(0.f); }
+        }
     } else {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 acc[m][n] = (m < cnt) ? *(const v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]) : splat(0.f);
+        if (a.mode != 0) request(min(next, n_rows - 1), tid);
+        else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { r1[k] = splat(0.f); r2[k] = splat(0.f); }
+        }
     }
     // ---- epilogue
     v4f s0[NT], s1v[NT], bias[NT];
@@ -274,6 +296,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
         for (int g = 0; g < KGC; ++g) wbot[g] = wb[(g * 2 + (wave & 1)) * 64];
         __syncthreads();
         bottleneck<NWAVE>(xs, wbot, a.bias2, a.out2 + (size_t)row * L * HPAD, L, wave, lane);
+    }
+    __syncthreads();                                             // the image (and sred) are free for the next read
     }
 }
 
@@ -498,7 +522,12 @@ int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
         hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
         return tiles;
     }
-    hipLaunchKernelGGL(train_row_kernel, dim3((unsigned)n_rows), dim3(SEG_THREADS), 0, s, a);
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    hipLaunchKernelGGL(train_row_kernel, dim3((unsigned)std::min(n_rows, n_cus)), dim3(SEG_THREADS), 0, s, a, n_rows);
     return n_rows;
 }
 
