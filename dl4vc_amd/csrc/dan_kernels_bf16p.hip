@@ -839,6 +839,12 @@ void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t
     const char* form_env = getenv("DAN_BF16_FORM");
     if (staggered_ok(a) && form_env && form_env[0] == 'q')
         hipLaunchKernelGGL(segmentq_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    // each position half owns MT tiles of 32 columns: the narrowest tiling that covers the window (201 columns on 2 x 5 tiles
+    // would spend 37 % of the MFMAs past column 201; 2 x 4 tiles 22 %)
+    else if (a.L <= 2 * 3 * 32)
+        hipLaunchKernelGGL((segmentp_kernel<3>), dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    else if (a.L <= 2 * 4 * 32)
+        hipLaunchKernelGGL((segmentp_kernel<4>), dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
     else
         hipLaunchKernelGGL((segmentp_kernel<5>), dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
 }

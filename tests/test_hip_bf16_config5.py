@@ -20,10 +20,11 @@ from oracle.dan_oracle import (dan_forward_oracle, random_state_dict, spec_from,
 
 pytestmark = pytest.mark.gpu
 
-R, L = 128, 301
+# (reads, window): BASELINE config 5, and two narrower windows that run the kernel's 2 x 4- and 2 x 3-tile instantiations
+SHAPES = [(128, 301), (64, 201), (24, 150)]
 
 
-def _sites():
+def _sites(R, L):
     """8 sites: six generated pileups (reads span ~225 of the 301 columns, placed uniformly: columns 209..300 are covered), one
     with its allele masks at the two window EDGES (columns 0 and 300) and reads that do / do not agree there, one all-padding."""
     b = synth.make_sites(8, reads=R, length=L, seed=41)
@@ -69,11 +70,12 @@ def _compare(got, want, what, min_identical=0.97, upstream=0.0):
     return frac
 
 
-@pytest.fixture(scope="module")
-def run():
+@pytest.fixture(scope="module", params=SHAPES, ids=lambda rl: "%dx%d" % rl)
+def run(request):
+    R, L = request.param
     cfg = DanConfig(reads=R, length=L, precision=PRECISION_BF16)
     sd = random_state_dict(cfg, seed=3)
-    planes = _sites()
+    planes = _sites(R, L)
     net = DanNet(cfg).load_state_dict(sd)
     assert net.handle.query("bf16_pingpong") == 1
     B = planes[0].shape[0]
@@ -139,7 +141,7 @@ def test_read_mean_and_feature_from_the_kernels_own_images(run):
     want = y2.mean(axis=1)                                                               # (B,L,128)
     assert np.abs(pool - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
     y7 = taps[7].astype(np.float64)
-    B = y7.shape[0]
+    B, L = y7.shape[0], cfg.length
     mx = y7.max(axis=1).transpose(0, 2, 1).reshape(B, -1)                                # channel-major, position-minor (model.py:833)
     av = y7.mean(axis=1).transpose(0, 2, 1).reshape(B, -1)
     n = 128 * L
@@ -204,7 +206,7 @@ def test_staggered_form_is_bit_identical_to_the_lockstep_form(run, monkeypatch):
     got = net.forward_u8(*planes, aux=True)
     net.handle.set_tap(cfg.layers)
     net.forward_u8(*planes)
-    B = planes[0].shape[0]
+    B, R, L = planes[0].shape
     tap7 = net.handle.read_buffer("tap", B * R * L * 128).reshape(B, R, L, 128)
     net.close()
     assert np.array_equal(tap7, taps[cfg.layers])

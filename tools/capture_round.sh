@@ -1,9 +1,14 @@
 #!/bin/bash
-# Every measured artefact of a round in one GPU-box call: tools/capture_round.sh r02   (then, here: python tools/summarize_profile.py r02)
+# Every measured artefact of a round, in two GPU-box calls (each fits gpurun's 20-minute limit):
+#   tools/capture_round.sh r03 a      default bench under rocprofv3 (kernel trace, PMC passes) + the bench lines of the other configurations
+#   tools/capture_round.sh r03 b      kernel traces and PMC passes of the bf16 config-5 command and of the training step
+# (then, here: python tools/summarize_profile.py r03 -- it also condenses the PMC passes of the bf16 and training commands)
 set -eo pipefail
-tag=${1:-r02}
+tag=${1:-r03}
+part=${2:-all}
 out=gpurun_out/lines_$tag
 mkdir -p "$out"
+if [ "$part" != b ]; then
 timeout -k 10 900 tools/profile_round.sh "$tag"
 timeout -k 10 300 python bench.py --reads 100 --sites 32768 --steps 3 --warmup 1 --no-cpu-baseline > "$out/fp32_100x201.json" 2> "$out/fp32_100x201.err"
 timeout -k 10 300 python bench.py --skip-empty-rows --steps 3 --warmup 1 --no-cpu-baseline > "$out/skip_empty_rows.json" 2> "$out/skip.err"
@@ -11,5 +16,14 @@ timeout -k 10 300 python bench.py --precision 1 --steps 3 --warmup 1 --no-cpu-ba
 timeout -k 10 300 python bench.py --precision 2 --reads 128 --window 301 --sites 16384 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bf16_128x301.json" 2> "$out/bf16.err"
 timeout -k 10 300 python bench.py --precision 2 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bf16_64x201.json" 2> "$out/bf16b.err"
 timeout -k 10 300 python bench.py --mode train --steps 10 --warmup 2 > "$out/train.json" 2> "$out/train.err"
+timeout -k 10 300 python bench.py --mode train --train-batch 10 --steps 20 --warmup 3 --no-cpu-baseline > "$out/train_b10.json" 2> "$out/train_b10.err"
+fi
+if [ "$part" = a ]; then echo captured part a; exit 0; fi
 timeout -k 10 300 tools/profile_train.sh "$tag" > "$out/train_kernels.txt" 2>&1
+# kernel trace of the bf16 config-5 command, then the PMC passes (own runs, counters only) of it and of the training step
+root=$PWD
+mkdir -p "gpurun_out/prof_bf16_$tag"
+( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_bf16_$tag/kt" -- python3 "$root/bench.py" --precision 2 --reads 128 --window 301 --sites 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path > "$root/gpurun_out/prof_bf16_$tag/bench_under_rocprof.json" 2> "$root/gpurun_out/prof_bf16_$tag/kt.log" )
+timeout -k 10 400 tools/profile_pmc.sh "pmc_bf16_$tag" --precision 2 --reads 128 --window 301 --sites 2048 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path
+timeout -k 10 400 tools/profile_pmc.sh "pmc_train_$tag" --mode train --steps 2 --warmup 1 --no-cpu-baseline
 echo captured

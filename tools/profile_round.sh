@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the rocprofv3 evidence kept under profiles/ (run on the GPU box from the repository root):
+# Regenerates the rocprofv3 evidence kept under profiles/ (run on the GPU box from the repository root; tools/capture_round.sh calls it):
 #   tools/profile_round.sh r01        -> gpurun_out/prof_r01/*, then `python tools/summarize_profile.py r01` writes profiles/
 # Kernel trace of the default bench command; FETCH_SIZE / WRITE_SIZE / SQ counters in their own --pmc passes of a short
 # bench (4096 sites = 32 chunks) -- counters are never combined with trace domains other than the kernel trace.
