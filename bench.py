@@ -29,6 +29,18 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; the bf16x3 path issues 
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(section, key):
+    """HBM bytes measured by the newest round's rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs of the same command,
+    committed as profiles/rNN_traffic.json -- counters cannot be collected inside the timed process); None when absent."""
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not tfiles:
+        return None
+    with open(tfiles[-1]) as f:
+        rec = json.load(f).get(section)
+    return int(rec[key]) if rec and key in rec else None
+
+
 def resolve_ranks(args, argv):
     """--gpus N is a promise about how many ranks take part; it is kept here or the run fails.
 
@@ -261,8 +273,10 @@ def bench_train(args):
                                "no exchange at N=1" if world == 1 else ("direct reduce-scatter + all-gather" if exchange.direct else "all-reduce")),
                            "gflop_per_site": round(flops_site / 1e9, 3)},
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                             "kernel": "whole step (train_row_kernel + train_wgrad_kernel dominate; profiles/r02_train_kernel_stats.csv)"},
+                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                             "traffic": pmc_traffic("train_step", "hbm_bytes_per_step") if B == 64 and cfg.length == 201 else None,
+                             "kernel": "whole step (train_row_kernel + train_wgrad_kernel + train_point_kernel dominate; per-kernel "
+                                       "durations and HBM bytes: profiles/rNN_train_kernel_stats.csv, rNN_train_pmc_summary.csv)"},
                 "last_step": {k: round(float(last[k]), 6) for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle.dan_train_oracle import train_step_oracle, TrainHyper as OH
@@ -455,12 +469,10 @@ def main():
         # HBM traffic of the dominant kernel: measured by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
         # of this same command and committed under profiles/ (PMC collection cannot run inside the timed process)
         traffic = None
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))      # the newest round's PMC passes
-        tpath = tfiles[-1] if tfiles else ""
-        if os.path.isfile(tpath) and cfg.reads == 64 and not args.chunk_sites and cfg.precision == 0 and cfg.length == 201:
-            with open(tpath) as f:
-                traffic = int(json.load(f)["segment_kernel_bytes_per_launch"]["total"])
+        if not args.chunk_sites and cfg.reads == 64 and cfg.precision == 0 and cfg.length == 201:
+            traffic = pmc_traffic("segment_kernel_bytes_per_launch", "total")
+        elif not args.chunk_sites and cfg.reads == 128 and cfg.precision == 2 and cfg.length == 301:
+            traffic = pmc_traffic("segmentp_kernel_bytes_per_launch", "total")
         sites_total = B * world * args.steps
         value = sites_total / elapsed
         # roofline of the dominant kernel (conv-stack segment kernel): algorithmic FLOPs = 2 x MAC of every

@@ -125,6 +125,61 @@ def main():
                 out.write("# %s: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) = %.4f\n"
                           % (k, r["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * r["SQ_BUSY_CU_CYCLES"])))
     print("wrote profiles/%s_*" % tag)
+    extras(tag, dst)
+
+
+def extras(tag, dst):
+    """Round 3 on: kernel traces and PMC passes of the bf16 config-5 command and of the training step (tools/capture_round.sh b),
+    the bench lines of the other configurations, and their HBM traffic appended to <tag>_traffic.json."""
+    import shutil
+    import subprocess
+    go = os.path.join(ROOT, "gpurun_out")
+    tpath = os.path.join(dst, tag + "_traffic.json")
+    traffic = json.load(open(tpath))
+    for name, what, cmd in (("train", "bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline   (tools/profile_train.sh)", None),
+                            ("bf16", "bench.py --precision 2 --reads 128 --window 301 --sites 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path", None)):
+        hits = sorted(glob.glob(os.path.join(go, "prof_%s_%s" % (name, tag), "kt", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+        if hits:
+            with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as out:
+                out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 %s   (kernel_stats.csv, verbatim)\n" % what)
+                out.write(open(hits[-1]).read())
+    pmc = {"train": ("--mode train --steps 2 --warmup 1 --no-cpu-baseline", 3),
+           "bf16": ("--precision 2 --reads 128 --window 301 --sites 2048 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path", 1)}
+    for name, (command, passes) in pmc.items():
+        src = os.path.join(go, "pmc_%s_%s" % (name, tag))
+        if not os.path.isdir(src):
+            continue
+        csv_out = os.path.join(dst, "%s_%s_pmc_summary.csv" % (tag, name))
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), src, csv_out, "--command", command])
+        rows = list(csv.DictReader(l for l in open(csv_out) if not l.startswith("#")))
+        if name == "train":
+            total = sum(float(r["hbm_bytes"]) * int(r["dispatches"]) for r in rows if r["hbm_bytes"] != "nan") / passes
+            traffic["train_step"] = {"command": "bench.py " + command, "hbm_bytes_per_step": total,
+                                     "note": "sum over every kernel of the step of (2 x FETCH_SIZE + WRITE_SIZE) per dispatch x dispatches, "
+                                             "/ %d steps; 64 sites x 100 reads x 201 bp" % passes}
+        else:
+            for r in rows:
+                if "segmentp_kernel" in r["kernel"]:
+                    traffic["segmentp_kernel_bytes_per_launch"] = {
+                        "command": "bench.py " + command, "total": float(r["hbm_bytes"]), "dispatches": int(r["dispatches"]),
+                        "note": "chunk of 512 sites x 128 reads x 301 bp, averaged over the two launches of a chunk (layers 1-2, layers 3-7)"}
+    json.dump(traffic, open(tpath, "w"), indent=1)
+    lines = os.path.join(go, "lines_" + tag)
+    for f in sorted(glob.glob(os.path.join(lines, "*.json"))):
+        ls = [l for l in open(f) if l.startswith("{")]
+        if ls:
+            rec = json.loads(ls[-1])
+            base = os.path.basename(f)[:-5]
+            if base == "train" and "train_step" in traffic:
+                rec["roofline"]["traffic"] = int(traffic["train_step"]["hbm_bytes_per_step"])
+            if base == "bf16_128x301" and "segmentp_kernel_bytes_per_launch" in traffic:
+                rec["roofline"]["traffic"] = int(traffic["segmentp_kernel_bytes_per_launch"]["total"])
+            with open(os.path.join(dst, "%s_bench_line_%s.json" % (tag, base)), "w") as out:
+                out.write(json.dumps(rec) + "\n")
+    gate = os.path.join(go, "genotype_gate.json")
+    if os.path.isfile(gate):
+        shutil.copy(gate, os.path.join(dst, tag + "_genotype_gate.json"))
+    print("wrote profiles/%s_* (bf16, training, lines)" % tag)
 
 
 if __name__ == "__main__":
