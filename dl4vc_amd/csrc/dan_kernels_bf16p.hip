@@ -97,6 +97,10 @@ __device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigne
     for (int j = 0; j < NA; ++j) a[j] = (j < 4) ? first[j] : w[(size_t)j * 4 * 64];   // (first four: requested a stage ahead by the caller)
 #pragma unroll
     for (int m = 0; m < MT; ++m) b[0][m] = lds_read(lds, xb0 + m * (32 * P_ROW_BYTES));
+    // (a hard fence: left in the region below, the first step's reads of tiles 1 .. MT-1 are the first "DS read"s the scheduling
+    // groups find -- every read of the whole walk then sits ONE MFMA ahead of its use instead of MT, each MFMA behind an
+    // s_waitcnt lgkmcnt(0) on a read issued 8 cycles earlier)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int sn = s + 1;
