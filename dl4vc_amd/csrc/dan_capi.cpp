@@ -180,7 +180,8 @@ uint16_t bf16_bits(float x) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-// MFMA 32x32x16 bf16 A-fragment order of the ping-pong kernel (dan_kernels.h): fragment ((t * 8 + ks) * nq + q), lane, j:
+// MFMA 32x32x16 bf16 A-fragment order of the ping-pong kernel (dan_kernels.h): fragment ((ks * taps + t) * nq + q), lane, j
+// (channel-group major: layer 1's three groups are the first nine steps of the walk):
 //   row m = lane & 31 -> output channel 32 q + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3),  k = 16 ks + 8 (lane >> 5) + j
 template <typename F>
 void pack_fragp(uint16_t* dst, int taps, int ksteps, int nq, F W);
@@ -192,7 +193,7 @@ void pack_fragp(uint16_t* dst, int taps, int ksteps, int nq, F W) {
     for (int t = 0; t < taps; ++t)
         for (int ks = 0; ks < ksteps; ++ks)
             for (int q = 0; q < nq; ++q) {
-                uint16_t* f = dst + ((size_t)(t * P_KSC + ks) * nq + q) * (WP_FRAG / 2);
+                uint16_t* f = dst + ((size_t)(ks * taps + t) * nq + q) * (WP_FRAG / 2);
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int m = lane & 31;

@@ -126,7 +126,7 @@ constexpr int P_KSC = CPAD / 16;          // 8
 // per-layer weight block (bytes): MFMA 32x32x16 A fragments, 1 KiB each ([lane 64][8 bf16]); the 32 rows of a fragment are the
 // output channels of one channel quarter q in the order row m -> channel 32 q + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3), so
 // that a lane's 16 accumulator registers are 16 CONSECUTIVE channels (32 q + 16 (lane >> 5) + reg)
-//   [WP_CONV_OFF) conv      [tap 3][kstep 8][q 4] fragments   (layer 1 uses ksteps 0..2)
+//   [WP_CONV_OFF) conv      [kstep 8][tap 3][q 4] fragments   (layer 1 uses ksteps 0..2: the first nine steps of the walk)
 //   [WP_RES_OFF)  residual  [kstep 8][q 4]
 //   [WP_BOT_OFF)  bottleneck [kstep 8]                         (32 outputs: one row tile)
 //   [WP_CST_OFF)  the fp32 constants of the layer (bias, scale, shift, bres, bbot), as in the other families

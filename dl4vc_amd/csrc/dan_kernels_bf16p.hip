@@ -74,16 +74,18 @@ __device__ __forceinline__ unsigned cell_addr(int row, int chunk) { return (unsi
 // acc[m] += W(this wave's 32 channels) x X(32 positions of tile m) over TAPS x KS k-steps of 16 channels.
 //   xb0..2: this lane's byte address of chunk (lane >> 5) of its row for tap t in the source image (tile 0); chunk
 //           2 ks + (lane >> 5) lies at xb ^ (ks << 5), tile m a further m * 32 rows on.
-//   w:      this wave's first fragment (+ lane); step (t, ks) is (t * P_KSC + ks) * 4 fragments on; first[] = steps 0..3.
+//   w:      this wave's first fragment (+ lane); the walk is CHANNEL-GROUP major: step s = ks * TAPS + t lies s * 4 fragments on;
+//           first[] = steps 0..3.  k_short (wave-uniform): only the first P_KS0 channel groups exist (layer 1's 48 encoded
+//           channels): the walk leaves after TAPS x P_KS0 steps -- one exit from the one unrolled shape, 45 MFMAs instead of 120.
 // A run-time loop over chunks of NA = 4 k-steps: the four weight fragments of the NEXT chunk are requested slot by slot as
 // the current chunk's are consumed (an L2 round trip = 4 x MT MFMAs ahead), the activations of the next k-step while the
 // current one's MFMAs issue (double-buffered registers, one ds_read_b128 behind each MFMA).
 template <int MT, int TAPS, bool FRONT>
 __device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8p w,
-                                       const bf8 (&first)[4]) {
+                                       const bf8 (&first)[4], bool k_short = false) {
     // Fully unrolled over TAPS x 8 k-steps (hipcc then counts its vmcnt waits exactly: a run-time chunk loop drained every
-    // outstanding weight fragment once per chunk).  ONE shape serves layer 1 too -- its 48 input channels run as 128 with zero
-    // weights -- because a second conv instance kept a second set of 80 accumulator registers alive.
+    // outstanding weight fragment once per chunk).  ONE shape serves layer 1 too -- a second conv instance kept a second set of
+    // 80 accumulator registers alive -- which leaves the walk early (k_short).
     // FRONT (the staggered form, where the wave has the SIMD's matrix pipe to itself): the NEXT k-step's activations are all
     // requested ahead of this step's MFMAs, pinned there by scheduling fences -- a full step of lead for every fragment.
     // Otherwise (two waves computing side by side cover each other's waits) one read behind each MFMA.
@@ -104,8 +106,12 @@ __device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigne
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int sn = s + 1;
-        const unsigned xt = (sn / P_KSC == 0) ? xb0 : (sn / P_KSC == 1) ? xb1 : xb2;
-        const unsigned xa = xt ^ (unsigned)((sn % P_KSC) << 5);
+        const unsigned xt = (sn % TAPS == 0) ? xb0 : (sn % TAPS == 1) ? xb1 : xb2;
+        const unsigned xa = xt ^ (unsigned)((sn / TAPS) << 5);
+        if (TAPS == 3 && s == TAPS * P_KS0) {
+            if (k_short) break;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (FRONT) {
             if (sn < S) {
 #pragma unroll
@@ -337,10 +343,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                 row[45] = row[46] = row[47] = 0.f;
                 const int r = P_HALO + p;
 #pragma unroll
-                for (int c = 0; c < CPAD / 8; ++c) {             // channels 48..127 as zeros: layer 1 runs as a 128-channel layer
+                for (int c = 0; c < CIN0 / 8; ++c) {             // (layer 1's walk reads these six chunks of a row only)
                     bf8 v;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (c * 8 + j < CIN0) ? (__bf16)row[(c * 8 + j) % CIN0] : (__bf16)0.f;
+                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)row[c * 8 + j];
                     lds_write(img, cell_addr(r, c), v);
                 }
             }
@@ -393,8 +399,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             }
             const unsigned xb0 = cell_addr(row0 - dil, hh), xb1 = cell_addr(row0, hh), xb2 = cell_addr(row0 + dil, hh);
             gbf8p wconv = (gbf8p)(blk + WP_CONV_OFF) + q * 64 + lane;
-            // (layer 1: the 48 encoded channels run as 128 -- zero weights beyond them, zeros in the image: see the encode stage)
-            gemm_p<MT, 3, false>(acc, src, xb0, xb1, xb2, wconv, pre_a);
+            gemm_p<MT, 3, false>(acc, src, xb0, xb1, xb2, wconv, pre_a, l == 0);
             PFENCE();
             PSTAMP(sb + 1);
 
