@@ -749,7 +749,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentq_kernel(Segmen
             }
             const unsigned xb0 = cell_addr(row0 - dil, hh), xb1 = cell_addr(row0, hh), xb2 = cell_addr(row0 + dil, hh);
             __builtin_amdgcn_s_setprio(3);                        // (the SIMD's other wave is in a vector stage: the matrix stream first)
-            gemm_p<Q_MT, 3, true>(acc, img, xb0, xb1, xb2, (gbf8p)(blk + WP_CONV_OFF) + q * 64 + lane, pre_a);
+            gemm_p<Q_MT, 3, false>(acc, img, xb0, xb1, xb2, (gbf8p)(blk + WP_CONV_OFF) + q * 64 + lane, pre_a);
             __builtin_amdgcn_s_setprio(0);
             PFENCE();
             // requests for the stages ahead ride under the barrier
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentq_kernel(Segmen
                 // ================= stage R: y = Wr t + (x + bres), t = the image
                 const unsigned xr = cell_addr(row0, hh);
                 __builtin_amdgcn_s_setprio(3);
-                gemm_p<Q_MT, 1, true>(acc, img, xr, xr, xr, (gbf8p)(blk + WP_RES_OFF) + q * 64 + lane, pre_a);
+                gemm_p<Q_MT, 1, false>(acc, img, xr, xr, xr, (gbf8p)(blk + WP_RES_OFF) + q * 64 + lane, pre_a);
                 __builtin_amdgcn_s_setprio(0);
                 PFENCE();
                 load_first(pre_a, (gbf8p)(blk_of(last_layer ? l : l + 1) + WP_CONV_OFF) + q * 64 + lane);
@@ -842,9 +842,11 @@ void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t
     wgs = (wgs + 7) / 8 * 8;
     const int need = ((a.slice_rows + 0) < 1 ? 1 : a.slice_rows) * 8;       // no more workgroups than rows per slice x 8
     if (wgs > need) wgs = need;
-    // DAN_BF16_FORM=q selects the staggered form (measured SLOWER, kept for A/B runs: a wave that has the matrix pipe to itself
-    // issues an MFMA every ~51 cycles -- each 1-KiB ds_read_b128 return and weight-fragment return costs the pipe several cycles and
-    // nothing covers its own waits -- so the hidden epilogues do not pay for its 20 % of redundant tiles: DESIGN.md)
+    // DAN_BF16_FORM=q selects the staggered form (measured SLOWER, 18.0 k vs 20.5 k sites/s on config 5; kept for A/B runs).  Its
+    // premise does not hold on this hardware: a vector instruction of the SIMD's OTHER wave delays this wave's MFMA walk by its
+    // full ~3.7 cycles, at any s_setprio (tools/ubench/gemm_p_lone.hip: 37.8 cycles per MFMA beside a parked partner, 46 / 56 / 70
+    // beside 300 / 600 / 1000 vector instructions) -- an epilogue beside a GEMM costs what it costs behind it, and the form pays
+    // 20 % of redundant tiles on top.  DESIGN.md section 11.1.
     const char* form_env = getenv("DAN_BF16_FORM");
     if (staggered_ok(a) && form_env && form_env[0] == 'q')
         hipLaunchKernelGGL(segmentq_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);

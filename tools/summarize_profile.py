@@ -176,6 +176,9 @@ def extras(tag, dst):
                 rec["roofline"]["traffic"] = int(traffic["segmentp_kernel_bytes_per_launch"]["total"])
             with open(os.path.join(dst, "%s_bench_line_%s.json" % (tag, base)), "w") as out:
                 out.write(json.dumps(rec) + "\n")
+    for f in sorted(glob.glob(os.path.join(lines, "*.txt"))):
+        if os.path.basename(f) != "train_kernels.txt":
+            shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, os.path.basename(f))))
     gate = os.path.join(go, "genotype_gate.json")
     if os.path.isfile(gate):
         shutil.copy(gate, os.path.join(dst, tag + "_genotype_gate.json"))
