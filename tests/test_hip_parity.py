@@ -224,7 +224,7 @@ def test_shape_errors_are_loud():
 def test_genotype_calls_identical_to_oracle():
     """North-star gate: genotype calls after the format_vcf stage are identical whether the scores come from the HIP path --
     fp32 Winograd (default), fp32 direct, bf16x3 -- or from the oracle, on 512 sites at production width.  The two score heads
-    are rescaled (as in smoke()) so that the probabilities are INTERIOR -- with seeded He-gain weights most softmaxes saturate
+    are re-standardised (per class, over the batch) so that the probabilities are INTERIOR and both genotypes occur -- with seeded He-gain weights most softmaxes saturate
     and a comparison of 0/1 values proves nothing -- and spread across the pipeline's thresholds (call 0.1 / 0.2, homozygous
     0.75 / 0.8, call_variants.sh:154-160).  A score tolerance cannot by itself guarantee calls on a knife edge (SURVEY.md
     section 7): the sites within 1e-4 of a threshold (dl4vc_amd.vcf.threshold_distance, the count main.py logs) are counted,
@@ -242,10 +242,14 @@ def test_genotype_calls_identical_to_oracle():
     hid = pre["hidden"].astype(np.float64)
     want = {}
     for head, key in (("fcHidden2VT", "vt_logits"), ("fcHidden2BinTarget", "bin_logits")):
-        g = np.float32(2.5 / max(1e-6, float(np.abs(pre[key]).max())))
-        sd[head + ".weight"] = sd[head + ".weight"] * g
-        sd[head + ".bias"] = sd[head + ".bias"] * g
-        want[key] = hid @ sd[head + ".weight"].astype(np.float64).T + sd[head + ".bias"].astype(np.float64)   # logits are linear in the head
+        # every class's logit standardised over the batch to mean 0, deviation 1.5 (a random head leaves one class far below the
+        # others: no site would ever be called homozygous): logits' = (logits - mean_c) * g_c, linear in the head
+        lg = pre[key].astype(np.float64)
+        g = (1.5 / np.maximum(lg.std(axis=0), 1e-6)).astype(np.float32)
+        w = np.asarray(sd[head + ".weight"], np.float32) * g[:, None]
+        b = ((np.asarray(sd[head + ".bias"], np.float64) - lg.mean(axis=0)) * g).astype(np.float32)
+        sd[head + ".weight"], sd[head + ".bias"] = w, b
+        want[key] = hid @ w.astype(np.float64).T + b.astype(np.float64)   # logits are linear in the head
     e = np.exp(want["vt_logits"] - want["vt_logits"].max(axis=1, keepdims=True))
     want["vt_prob"] = e / e.sum(axis=1, keepdims=True)
     eb = np.exp(want["bin_logits"] - want["bin_logits"].max(axis=1, keepdims=True))
@@ -265,6 +269,7 @@ def test_genotype_calls_identical_to_oracle():
     ref_calls = calls(want)
     pos = [r.split("\t")[1] for r in batch.vcfrec]
     report = {"sites": n_sites, "interior_probability_sites": interior, "called_by_oracle": len(ref_calls),
+              "genotypes_by_oracle": {g: list(ref_calls.values()).count(g) for g in sorted(set(ref_calls.values()))},
               "within_1e-4_of_a_threshold": int(near.sum()), "paths": {}}
     for name, c in (("fp32_winograd", cfg), ("fp32_direct", dataclasses.replace(cfg, conv_algo=1)),
                     ("bf16x3", dataclasses.replace(cfg, precision=1))):
