@@ -32,5 +32,6 @@ DAN_BF16_FORM=p timeout -k 10 60 /tmp/segp_probe.bin 0 2 301 > "$out/segp_probe_
 DAN_BF16_FORM=p timeout -k 10 60 /tmp/segp_probe.bin 2 7 301 > "$out/segp_probe_segment2.txt" 2>&1
 hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_bf16_feed.hip -o /tmp/mfma_bf16_feed.bin 2> /dev/null
 hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_alone.hip -o /tmp/gemm_p_alone.bin 2> /dev/null
-( timeout -k 10 60 /tmp/mfma_bf16_feed.bin && timeout -k 10 60 /tmp/gemm_p_alone.bin ) > "$out/ubench_mfma_bf16.txt" 2>&1
+hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_lone.hip -o /tmp/gemm_p_lone.bin 2> /dev/null
+( timeout -k 10 60 /tmp/mfma_bf16_feed.bin && timeout -k 10 60 /tmp/gemm_p_alone.bin && timeout -k 10 60 /tmp/gemm_p_lone.bin ) > "$out/ubench_mfma_bf16.txt" 2>&1
 echo captured

@@ -12,7 +12,7 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(1))) bf8* gbf8p;
 constexpr int MT = 5, S = 24, NA = 4;
 
-template <int LDS, int W>
+template <int LDS, int W, int NV = 0>
 __global__ __launch_bounds__(512, 2) void k(const bf8* __restrict__ wts, float* out, int iters, unsigned long long* cyc) {
     __shared__ __attribute__((aligned(16))) char lds[159744];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -30,6 +30,8 @@ __global__ __launch_bounds__(512, 2) void k(const bf8* __restrict__ wts, float* 
     v16f acc[MT];
     for (int m = 0; m < MT; ++m) acc[m] = (v16f)(0.f);
     bf8 a[NA], b[2][MT];
+    float f[8];
+    for (int j = 0; j < 8; ++j) f[j] = (float)(tid + j);
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         for (int j = 0; j < NA; ++j) a[j] = w[(size_t)j * 4 * 64];
@@ -43,12 +45,15 @@ __global__ __launch_bounds__(512, 2) void k(const bf8* __restrict__ wts, float* 
             for (int m = 0; m < MT; ++m) {
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % NA], b[LDS ? (s & 1) : 0][m], acc[m], 0, 0, 0);
                 if (LDS && sn < S) b[sn & 1][m] = *(const bf8*)(lds + xa + m * 8192);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) f[v % 8] = f[v % 8] * 1.0001f + 0.5f;        // the SAME wave's vector work between its MFMAs
             }
             if (W && s + NA < S) a[s % NA] = w[(size_t)(s + NA) * 4 * 64];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (LDS && sn < S) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
             }
             if (W && s + NA < S) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
@@ -56,15 +61,16 @@ __global__ __launch_bounds__(512, 2) void k(const bf8* __restrict__ wts, float* 
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float sum = 0.f;
+    for (int j = 0; j < 8; ++j) sum += f[j];
     for (int m = 0; m < MT; ++m) for (int j = 0; j < 16; ++j) sum += acc[m][j];
     out[(size_t)blockIdx.x * blockDim.x + tid] = sum;
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int LDS, int W>
+template <int LDS, int W, int NV = 0>
 static void run(const char* name, int threads, const bf8* dw, float* dout, unsigned long long* dcyc) {
     const int iters = 200, wgs = 256;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<LDS, W>), dim3(wgs), dim3(threads), 0, 0, dw, dout, iters, dcyc);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<LDS, W, NV>), dim3(wgs), dim3(threads), 0, 0, dw, dout, iters, dcyc);
     hipDeviceSynchronize();
     std::vector<unsigned long long> c(wgs * 8);
     hipMemcpy(c.data(), dcyc, c.size() * 8, hipMemcpyDeviceToHost);
@@ -87,6 +93,12 @@ int main() {
     run<1, 0>("LDS reads", 512, dw, dout, dcyc);
     run<0, 1>("weight loads", 512, dw, dout, dcyc);
     run<1, 1>("LDS reads + weight loads", 512, dw, dout, dcyc);
+    run<1, 1, 2>("feeds + 2 own vector instr per MFMA", 512, dw, dout, dcyc);
+    run<1, 1, 4>("feeds + 4 own vector instr per MFMA", 512, dw, dout, dcyc);
+    run<1, 1, 6>("feeds + 6 own vector instr per MFMA", 512, dw, dout, dcyc);
+    run<1, 1, 2>("feeds + 2 own vector instr per MFMA", 256, dw, dout, dcyc);
+    run<1, 1, 4>("feeds + 4 own vector instr per MFMA", 256, dw, dout, dcyc);
+    run<1, 1, 6>("feeds + 6 own vector instr per MFMA", 256, dw, dout, dcyc);
     run<0, 0>("no feeds", 256, dw, dout, dcyc);
     run<1, 1>("LDS reads + weight loads", 256, dw, dout, dcyc);
     return 0;
