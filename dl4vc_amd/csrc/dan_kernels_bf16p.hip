@@ -517,7 +517,21 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
         {
             const char* img = lds + cur * P_IMG_BYTES;
             bf8* ydst = (bf8*)(a.y + read_idx * (size_t)L * CPAD);
-            for (int i = tid; i < L * (CPAD / 8); i += SEG_THREADS) ydst[i] = lds_read(img, cell_addr(P_HALO + (i >> 4), i & 15));
+            // every chunk of the thread read before the first is stored (the accumulators are dead: registers are free) -- as a
+            // loop of read -> wait -> store the stage was ten LDS round trips long.  (Storing y from the last epilogue's registers
+            // instead, with no copy-out stage at all, was tried: 25 spilled registers, reloads inside the conv GEMM, -6 %.)
+            constexpr int NC = (P_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;     // 10
+            bf8 v[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int i = tid + k * SEG_THREADS;
+                v[k] = lds_read(img, cell_addr(P_HALO + min(i >> 4, P_LMAX - 1), i & 15));
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int i = tid + k * SEG_THREADS;
+                if (i < L * (CPAD / 8)) ydst[i] = v[k];
+            }
         }
         if (resumed && a.pool && next_row >= 0) seed_request(next_row, lane);
         PSTAMP(63);
