@@ -627,21 +627,48 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                 const float* pa = sa + kk * WG_S + i16;
                 const float* pb = sb + (HALO + kk) * WG_S + i16;
                 const int dstep = a.dil * WG_S;
-#pragma unroll 2
-                for (int k4 = 0; k4 < WG_CH / 4; ++k4) {
-                    float av[NA], bv[TAPS][NB];
+                // Software-pipelined over the k-steps: step k4 + 1's operands (NA + TAPS x NB one-float LDS reads) are requested
+                // while step k4's MFMAs issue, into the other register set; one read behind each MFMA, pinned by scheduling
+                // groups.  (Left to itself hipcc keeps ONE register pair for the B operands: ds_read2_b32, s_waitcnt lgkmcnt(0),
+                // two MFMAs, again -- every pair of MFMAs behind an exposed LDS round trip: MFMA busy 0.67, waits 0.42.)
+                constexpr int NSTEP = WG_CH / 4;
+                static_assert(NSTEP % 2 == 0, "the two register sets alternate over pairs of k-steps");
+                float av[2][NA], bv[2][TAPS][NB];
+                auto fetch = [&](int k4, float (&A)[NA], float (&B)[TAPS][NB]) {
 #pragma unroll
-                    for (int x = 0; x < NA; ++x) av[x] = pa[4 * k4 * WG_S + 16 * (OWN_O ? wave : x)];
+                    for (int x = 0; x < NA; ++x) A[x] = pa[4 * k4 * WG_S + 16 * (OWN_O ? wave : x)];
 #pragma unroll
                     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                        for (int y = 0; y < NB; ++y) bv[t][y] = pb[4 * k4 * WG_S + (t - TAPS / 2) * dstep + 16 * (OWN_O ? y : wave)];
+                        for (int y = 0; y < NB; ++y) B[t][y] = pb[4 * k4 * WG_S + (t - TAPS / 2) * dstep + 16 * (OWN_O ? y : wave)];
+                };
+                auto mfmas = [&](const float (&A)[NA], const float (&B)[TAPS][NB]) {
 #pragma unroll
                     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
                         for (int y = 0; y < NB; ++y)
 #pragma unroll
-                            for (int x = 0; x < NA; ++x) acc[t][x][y] = mfma16(av[x], bv[t][y], acc[t][x][y]);
+                            for (int x = 0; x < NA; ++x) acc[t][x][y] = mfma16(A[x], B[t][y], acc[t][x][y]);
+                };
+                auto pipeline = [&]() {
+#pragma unroll
+                    for (int i = 0; i < TAPS * NB * NA; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NA + TAPS * NB, 0);      // (the reads no MFMA carried)
+                };
+                fetch(0, av[0], bv[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int k4 = 0; k4 < NSTEP; k4 += 2) {
+                    fetch(k4 + 1, av[1], bv[1]);
+                    mfmas(av[0], bv[0]);
+                    pipeline();
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(min(k4 + 2, NSTEP - 1), av[0], bv[0]);                        // (last pair: a harmless re-read)
+                    mfmas(av[1], bv[1]);
+                    pipeline();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
