@@ -53,6 +53,7 @@ struct dan_handle {
     float* d_wl = nullptr;                   // [layers][LAYER_STRIDE] weight blocks (fp32 path)
     char* d_wl16 = nullptr;                  // [layers][W16_LAYER_BYTES] bf16 hi/lo weight blocks (precision 1, 2)
     char* d_wlp = nullptr;                   // [layers][WP_LAYER_BYTES] 32x32x16 fragments of the ping-pong bf16 kernel (precision 2)
+    char* d_wlr = nullptr;                   // the same blocks as 16x16x32 fragments (sixteen-wave form, DAN_BF16_FORM=r)
     float* d_wc16 = nullptr;                 // compression weights in the channel order of a 16-byte bf16 load of h
     float *d_wpool = nullptr, *d_cols = nullptr, *d_cp = nullptr, *d_zero = nullptr;   // conv(read-mean): weights [segment][128][384], scratch, result
     bool use_p = false;                      // precision 2 on dan_kernels_bf16p.hip: y and h cross HBM as bf16
@@ -199,6 +200,24 @@ void pack_fragp(uint16_t* dst, int taps, int ksteps, int nq, F W) {
                         const int m = lane & 31;
                         const int o = 32 * q + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
                         f[lane * 8 + j] = bf16_bits(W(o, 16 * ks + 8 * (lane >> 5) + j, t));
+                    }
+            }
+}
+
+// MFMA 16x16x32 bf16 A-fragment order of the sixteen-wave form: fragment ((ks * taps + t) * n_ct + ct), lane, j with
+//   row r = lane & 15 of channel tile ct -> output channel 32 (ct >> 1) + 8 (r >> 2) + 4 (ct & 1) + (r & 3)   (a lane's two tiles of a
+//   column are 8 consecutive channels),  k = 32 ks + 8 (lane >> 4) + j
+template <typename F>
+void pack_fragr(uint16_t* dst, int taps, int ksteps, int n_ct, F W) {
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int t = 0; t < taps; ++t)
+            for (int ct = 0; ct < n_ct; ++ct) {
+                uint16_t* f = dst + ((size_t)(ks * taps + t) * n_ct + ct) * (WP_FRAG / 2);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = lane & 15;
+                        const int o = 32 * (ct >> 1) + 8 * (r >> 2) + 4 * (ct & 1) + (r & 3);
+                        f[lane * 8 + j] = bf16_bits(W(o, 32 * ks + 8 * (lane >> 4) + j, t));
                     }
             }
 }
@@ -360,6 +379,7 @@ int dan_finalize(dan_t* h) {
         h->use_p = ok;
     }
     std::vector<char> wlp(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
+    std::vector<char> wlr(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
     std::vector<float> wpool_all(h->use_p ? (size_t)h->n_segments * CPAD * 3 * CPAD : 0, 0.f);
     std::vector<float> wc16_all;
     const size_t wc16_layer = (size_t)L * 2 * 2 * 64 * 4;    // floats: [pos][n 2][plane 2][lane 64][8 bf16]
@@ -408,6 +428,8 @@ int dan_finalize(dan_t* h) {
         }
         char* blkp = h->use_p ? wlp.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
         if (blkp) pack_fragp((uint16_t*)(blkp + WP_CONV_OFF), 3, l == 0 ? P_KS0 : P_KSC, 4, Wf);
+        char* blkr = h->use_p ? wlr.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
+        if (blkr) pack_fragr((uint16_t*)(blkr + WP_CONV_OFF), 3, l == 0 ? 2 : 4, 8, Wf);
         if (blkp && l > 0)
             for (int sg = 1; sg < h->n_segments; ++sg)
                 if (h->seg_begin[sg] == l) {                     // the layer behind a pool layer: its bf16-rounded weights, [o][t * 128 + c]
@@ -439,6 +461,7 @@ int dan_finalize(dan_t* h) {
             std::copy(pr.begin(), pr.end(), blk + WRES_OFF);
             if (blk16) pack_frag16((uint16_t*)(blk16 + W16_RES_OFF), W16_RES_FRAGS, 1, KG16_C, KGC, Wr);
             if (blkp) pack_fragp((uint16_t*)(blkp + WP_RES_OFF), 1, P_KSC, 4, Wr);
+            if (blkr) pack_fragr((uint16_t*)(blkr + WP_RES_OFF), 1, 4, 8, Wr);
             for (int o = 0; o < cout; ++o) cst[CST_BRES + o] = br->data[o];
             h->res_mask |= 1u << l;
         }
@@ -451,6 +474,7 @@ int dan_finalize(dan_t* h) {
             std::copy(pb.begin(), pb.end(), blk + WBOT_OFF);
             if (blk16) pack_frag16((uint16_t*)(blk16 + W16_BOT_OFF), W16_BOT_FRAGS, 1, KG16_C, 2, Wb);
             if (blkp) pack_fragp((uint16_t*)(blkp + WP_BOT_OFF), 1, P_KSC, 1, Wb);
+            if (blkr) pack_fragr((uint16_t*)(blkr + WP_BOT_OFF), 1, 4, 2, Wb);
             for (int o = 0; o < H; ++o) cst[CST_BBOT + o] = bb->data[o];
             const std::string z = "conv1D_compression_layers." + std::to_string(l);
             const Tensor* wcm = need(h, z + ".weight", {H, H, 1, L}, &rc); if (!wcm) return rc;
@@ -484,9 +508,14 @@ int dan_finalize(dan_t* h) {
     }
     if (h->use_p) {
         for (int l = 0; l < c.layers; ++l)
+        {
             memcpy(wlp.data() + (size_t)l * WP_LAYER_BYTES + WP_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
                    CST_FLOATS * sizeof(float));
+            memcpy(wlr.data() + (size_t)l * WP_LAYER_BYTES + WP_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
+                   CST_FLOATS * sizeof(float));
+        }
         if ((rc = dev_upload(h, &h->d_wlp, wlp))) return rc;
+        if ((rc = dev_upload(h, &h->d_wlr, wlr))) return rc;
         if (H > 0 && (rc = dev_upload(h, &h->d_wc16, wc16_all))) return rc;
         if (h->n_segments > 1) {
             if ((rc = dev_upload(h, &h->d_wpool, wpool_all))) return rc;
@@ -629,7 +658,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                     launch_segment(a, ns, h->n_cus, s);
                 } else if (h->use_p) {
                     SegmentPArgs b{};
-                    b.wl = h->d_wlp; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
+                    b.wl = h->d_wlp; b.wlr = h->d_wlr; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
                     b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
                     b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;

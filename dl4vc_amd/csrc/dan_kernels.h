@@ -139,6 +139,7 @@ constexpr int WP_LAYER_BYTES = WP_CST_OFF + (CST_FLOATS + 32) * 4;
 
 struct SegmentPArgs {
     const char* wl;              // [layers][WP_LAYER_BYTES]
+    const char* wlr;             // the same blocks in the sixteen-wave form's fragment order (16x16x32 tiles), or nullptr
     int l_begin, l_end, n_layers, dil_mid, dil_final;
     unsigned res_mask;
     int has_hw;

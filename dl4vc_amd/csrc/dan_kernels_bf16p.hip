@@ -45,8 +45,10 @@ __device__ unsigned long long* g_pstamps;
         if (lane == 0 && k == jw + 2 * nj && (k_) < 64) g_pstamps[((size_t)blockIdx.x * NWAVE + wave) * 64 + (k_)] = t_; \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
+#define RSTAMP(k_) do { if (wave < NWAVE) PSTAMP(k_); } while (0)
 #else
 #define PSTAMP(k) do {} while (0)
+#define RSTAMP(k) do {} while (0)
 #endif
 
 __device__ __forceinline__ v16f mfma32(bf8 a, bf8 b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -540,6 +542,390 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
 }
 
 // ================================================================================================
+// Sixteen-wave form (DAN_BF16_FORM=r): the same two images, stages and barriers as segmentp_kernel, on FOUR waves per SIMD.
+// v_mfma_f32_16x16x32_bf16: a 16-column tile costs a wave 4 accumulator registers per 16 channels, so a wave of
+// (channel quarter q, position quarter) = 32 channels x PT tiles of 16 columns holds 8 PT accumulators (40 at PT = 5) and the
+// whole wave fits 128 registers.  Why: the lockstep form's SIMDs idle ~25 % of the time with BOTH waves in a wait (L2 round
+// trips of the bottleneck weights, LDS store drains, pipeline fills); four waves leave fewer such moments.  The instruction
+// counts per SIMD are the same.  Weight rows are permuted (dan_capi.cpp::pack_fragr) so that a lane's 2 x 4 accumulators of a
+// column are 8 CONSECUTIVE channels: one 16-byte LDS store per tile.
+//   lane (n = lane & 15, g = lane >> 4):  B fragment = chunk 4 ks + g of row n (k = 32 ks + 8 g + j),
+//   C: column n, rows 4 g + i of channel tile e  ->  channel 32 q + 8 g + 4 e + i.
+// ================================================================================================
+constexpr int R_WAVES = 16, R_THREADS = R_WAVES * 64;
+constexpr int R_KS = CPAD / 32;               // 4 k-steps of 32 channels
+constexpr int R_KS0 = (CIN0 + 31) / 32;       // 2 for layer 1's 48 encoded channels (the upper 16 of the second step read zeros)
+typedef const __attribute__((address_space(1))) bf8* gbf8r;
+__device__ __forceinline__ v4f mfma16r(bf8 a, bf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// acc[e][t] += W(channel tile 2 q + e) x X(16 columns of tile t) over TAPS x 4 k-steps; channel-group-major walk (step = ks * TAPS + tap),
+// fragment (step * 8 + channel tile) of the layer block; two steps of weights in flight, the next step's activations one read
+// behind every second MFMA.
+template <int PT, int TAPS>
+__device__ __forceinline__ void gemm_r(v4f (&acc)[2][PT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8r w,
+                                       const bf8 (&first)[2][2], bool k_short = false) {
+    // weight steps in flight: two, or one at five tiles (40 accumulators + two activation sets of 20 leave no room for 16 more
+    // registers in a 128-register wave; a step is 10 MFMAs x 4 waves = ~640 cycles, about an L2 round trip)
+    constexpr int NA = PT >= 5 ? 1 : 2, S = TAPS * R_KS;
+    bf8 a[NA][2], b[2][PT];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { a[j][0] = first[j][0]; a[j][1] = first[j][1]; }
+#pragma unroll
+    for (int t = 0; t < PT; ++t) b[0][t] = lds_read(lds, xb0 + t * (16 * P_ROW_BYTES));
+    __builtin_amdgcn_sched_barrier(0);                          // (see gemm_p: the up-front reads must not join the groups below)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int sn = s + 1;
+        const unsigned xt = (sn % TAPS == 0) ? xb0 : (sn % TAPS == 1) ? xb1 : xb2;
+        const unsigned xa = xt ^ (unsigned)((sn / TAPS) << 6);
+        if (TAPS == 3 && s == TAPS * R_KS0) {
+            if (k_short) break;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bf8 an[2];
+        if (NA == 1 && sn < S) { an[0] = w[(size_t)sn * 8 * 64]; an[1] = w[(size_t)sn * 8 * 64 + 64]; }   // (requested ahead of the step's MFMAs)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            acc[0][t] = mfma16r(a[s % NA][0], b[s & 1][t], acc[0][t]);
+            acc[1][t] = mfma16r(a[s % NA][1], b[s & 1][t], acc[1][t]);
+            if (sn < S) b[sn & 1][t] = lds_read(lds, xa + t * (16 * P_ROW_BYTES));
+        }
+        if (NA == 1) {
+            if (sn < S) { a[0][0] = an[0]; a[0][1] = an[1]; }
+        } else if (s + NA < S) {
+            a[s % NA][0] = w[(size_t)(s + NA) * 8 * 64];
+            a[s % NA][1] = w[(size_t)(s + NA) * 8 * 64 + 64];
+        }
+        if (NA == 1 && sn < S) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (sn < S) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (NA != 1 && s + NA < S) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+}
+
+__device__ __forceinline__ void load_first_r(bf8 (&f)[2][2], gbf8r w) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { f[j][0] = w[(size_t)j * 8 * 64]; f[j][1] = w[(size_t)j * 8 * 64 + 64]; }
+}
+__device__ __forceinline__ void lds8(float (&v)[8], const float* p) {        // 8 consecutive floats from LDS
+    const v4f t0 = *(const v4f*)p, t1 = *(const v4f*)(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = t0[j]; v[4 + j] = t1[j]; }
+}
+__device__ __forceinline__ bf8 pack8(const float (&v)[8]) {
+    bf8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+    return o;
+}
+
+// h = relu(Wb y + bb), 128 -> 32, 16-column tiles dealt over the sixteen waves (tile tl lies tl * 4 KiB into the image: 16 rows
+// on the swizzle repeats); a lane's two channel tiles of a column are 8 consecutive outputs: one 16-byte store
+template <int PT>
+__device__ __forceinline__ void bottleneck_r(const char* img, const char* blk, uint16_t* hrow, int L, int wave, int lane) {
+    constexpr int NT = 4 * PT, NTL = (NT + R_WAVES - 1) / R_WAVES;
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+    // the weights are requested HERE, not a stage ahead as in the eight-wave form: 32 registers held through the epilogue do not
+    // fit a 128-register wave (tried three ways: 72-177 spilled registers, reloaded one per MFMA)
+    gbf8r wbot = (gbf8r)(blk + WP_BOT_OFF) + lane;
+    bf8 wb[R_KS][2];
+#pragma unroll
+    for (int ks = 0; ks < R_KS; ++ks) { wb[ks][0] = wbot[(ks * 2) * 64]; wb[ks][1] = wbot[(ks * 2 + 1) * 64]; }
+    const float* bp = (const float*)(blk + WP_CST_OFF) + CST_BBOT + 8 * g;
+    const v4f bb0 = *(const v4f*)bp, bb1 = *(const v4f*)(bp + 4);
+    const unsigned xa0 = cell_addr(P_HALO + n, g);
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int tl = wave + R_WAVES * i;
+        if (tl >= NT) break;                                     // (wave-uniform)
+        const char* tile = img + tl * (16 * P_ROW_BYTES);
+        bf8 bx[R_KS];
+#pragma unroll
+        for (int ks = 0; ks < R_KS; ++ks) bx[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 6));
+        v4f h0 = bb0, h1 = bb1;
+#pragma unroll
+        for (int ks = 0; ks < R_KS; ++ks) { h0 = mfma16r(wb[ks][0], bx[ks], h0); h1 = mfma16r(wb[ks][1], bx[ks], h1); }
+        const int p = 16 * tl + n;
+        if (p < L) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = relu1(h0[j]); v[4 + j] = relu1(h1[j]); }
+            *(bf8*)(hrow + (size_t)p * HPAD + 8 * g) = pack8(v);
+        }
+    }
+}
+
+template <int PT>
+__global__ __launch_bounds__(R_THREADS, 1) void segmentr_kernel(SegmentPArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[P_LDS_BYTES];
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int q = wave & 3, pq = wave >> 2;
+    const int L = a.L;
+    const int pbase = pq * (PT * 16);
+    auto cbuf = [&](int l) { return (float*)(lds + 2 * P_IMG_BYTES + (l & 1) * 2048); };
+    for (int i = tid0; i < P_LDS_BYTES / 16; i += R_THREADS) *(v4f*)(lds + (size_t)i * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int n_work = a.work_count ? *a.work_count : a.n_rows;
+    const int slice = a.work_count ? (n_work + 7) / 8 : a.slice_rows;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    auto row_of = [&](int k) {
+        const int wk = xcd * slice + k;
+        if (k >= slice || wk >= n_work) return -1;
+        return a.work_count ? a.work[wk] : wk;
+    };
+    const bool resumed = a.l_begin > 0;
+    auto dma_read = [&](int row_index, int img_i, int lane) {
+        const char* ysrc = (const char*)(a.y + (size_t)row_index * (size_t)L * CPAD);
+        char* img = lds + img_i * P_IMG_BYTES + P_HALO * P_ROW_BYTES;
+        for (int kb = wave; kb * 4 < L; kb += R_WAVES) {
+            const int p = 4 * kb + (lane >> 4), r = P_HALO + p;
+            if (p < L) glds16(ysrc + (size_t)p * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
+        }
+    };
+    v4f acc[2][PT];
+    auto seed_request = [&](int row_index, int lane) {
+        const int n = lane & 15, g = lane >> 4;
+        const float* cp = a.pool + (size_t)(row_index / a.R) * (size_t)L * CPAD + 32 * q + 8 * g;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int p = pbase + 16 * t + n;
+            if (p < L) { acc[0][t] = *(const v4f*)(cp + (size_t)p * CPAD); acc[1][t] = *(const v4f*)(cp + (size_t)p * CPAD + 4); }
+            else { acc[0][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[1][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+        }
+    };
+    int dma_img = 0;
+    if (resumed) {
+        const int r0 = __builtin_amdgcn_readfirstlane(row_of(jw));
+        if (r0 >= 0) {
+            dma_read(r0, 0, tid0 & 63);
+            if (a.pool) seed_request(r0, tid0 & 63);
+        }
+    }
+    for (int k = jw; k < slice; k += nj) {
+        const int row_index = __builtin_amdgcn_readfirstlane(row_of(k));
+        if (row_index < 0) break;
+        const int next_row = __builtin_amdgcn_readfirstlane(row_of(k + nj));
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int n = lane & 15, g = lane >> 4;
+        const int site = row_index / a.R;
+        const size_t read_idx = (size_t)row_index;
+        int cur = resumed ? dma_img : 0;
+        auto blk_of = [&](int l) { return a.wlr + (size_t)l * WP_LAYER_BYTES; };
+        v4f creq;
+        auto cst_request = [&](int l) { if (tid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WP_CST_OFF) + tid * 4); };
+        auto cst_put = [&](int l) { if (tid < 128) *(v4f*)(cbuf(l) + tid * 4) = creq; };
+        RSTAMP(0);
+        cst_request(a.l_begin);
+        const int c0 = 32 * q + 8 * g;                            // this lane's 8 output channels
+        const int row0 = P_HALO + pbase + n;                      // its row in tile 0
+        const unsigned wa = cell_addr(row0, 4 * q + g);           // its output chunk
+        bf8 pre_a[2][2];
+        load_first_r(pre_a, (gbf8r)(blk_of(a.l_begin) + WP_CONV_OFF) + 2 * q * 64 + lane);
+        if (!resumed) {
+            char* img = lds;
+            const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+            int ok_ref = 1, ok_var = 1;
+            for (int p = tid; p < L; p += R_THREADS) {
+                const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+                ok_ref &= (rm == 0) || (tok == rm);
+                ok_var &= (vm == 0) || (tok == vm);
+            }
+            int* flags = (int*)cbuf(a.l_begin + 1);
+            {
+                const int w_ref = __all(ok_ref), w_var = __all(ok_var);
+                if (lane == 0) { flags[wave] = w_ref; flags[R_WAVES + wave] = w_var; }
+            }
+            __syncthreads();
+            int agree_ref = 1, agree_var = 1;
+#pragma unroll
+            for (int w8 = 0; w8 < R_WAVES; ++w8) { agree_ref &= flags[w8]; agree_var &= flags[R_WAVES + w8]; }
+            for (int p = tid; p < L; p += R_THREADS) {
+                const int tok = a.reads[rbase + p], qv = a.qual[rbase + p], st = a.strand[rbase + p];
+                const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+                const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
+                const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
+                const float* pp = a.pe + p * EMBED;
+                float row[64];
+#pragma unroll
+                for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
+                row[40] = (float)qv * 0.01f;
+                row[41] = (float)st * 0.5f;
+                row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
+                row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
+                row[44] = (rm != 0) ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 45; c < 64; ++c) row[c] = 0.f;      // (layer 1's second 32-channel step reads chunks 4..7: 6, 7 as zeros)
+                const int r = P_HALO + p;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    bf8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)row[c * 8 + j];
+                    lds_write(img, cell_addr(r, c), v);
+                }
+            }
+        }
+        cst_put(a.l_begin);
+        if (resumed) __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        RSTAMP(1);
+        auto copy_tap = [&](int img_i, int nch) {
+            float* dst = a.tap + read_idx * (size_t)L * CPAD;
+            const char* img = lds + img_i * P_IMG_BYTES;
+            for (int i = tid; i < L * (CPAD / 8); i += R_THREADS) {
+                const int p = i >> 4, c = i & 15;
+                const bf8 v = lds_read(img, cell_addr(P_HALO + p, c));
+                v4f o0, o1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o0[j] = (c * 8 + j < nch) ? (float)v[j] : 0.f; o1[j] = (c * 8 + 4 + j < nch) ? (float)v[4 + j] : 0.f; }
+                *(v4f*)(dst + (size_t)i * 8) = o0;
+                *(v4f*)(dst + (size_t)i * 8 + 4) = o1;
+            }
+        };
+        if (a.tap && a.tap_layer == 0 && !resumed) copy_tap(0, CIN0);
+
+        for (int l = a.l_begin; l < a.l_end; ++l) {
+            const char* blk = blk_of(l);
+            const float* lc = cbuf(l);
+            const bool residual = (a.res_mask >> l) & 1u;
+            const bool last_layer = l + 1 == a.l_end;
+            const bool defer = a.has_hw && l > a.l_begin;
+            const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
+            const char* src = lds + cur * P_IMG_BYTES;
+            char* dst = lds + (cur ^ 1) * P_IMG_BYTES;
+            [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+            RSTAMP(sb + 0);
+            PFENCE();
+            if (!last_layer) cst_request(l + 1);
+            {
+                float bias[8];
+                lds8(bias, lc + CST_BIAS + c0);
+                const v4f b0 = {bias[0], bias[1], bias[2], bias[3]}, b1 = {bias[4], bias[5], bias[6], bias[7]};
+                if (l == a.l_begin && resumed && a.pool) {
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) { acc[0][t] += b0; acc[1][t] += b1; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) { acc[0][t] = b0; acc[1][t] = b1; }
+                }
+            }
+            const unsigned xb0 = cell_addr(row0 - dil, g), xb1 = cell_addr(row0, g), xb2 = cell_addr(row0 + dil, g);
+            gbf8r wconv = (gbf8r)(blk + WP_CONV_OFF) + 2 * q * 64 + lane;
+            gemm_r<PT, 3>(acc, src, xb0, xb1, xb2, wconv, pre_a, l == 0);
+            PFENCE();
+            RSTAMP(sb + 1);
+            auto store_tile = [&](char* img, int t, const float (&v)[8]) {
+                const int p = pbase + 16 * t + n;
+                bf8 o = pack8(v);
+                if (pbase + 16 * t + 16 > L) {                    // (uniform) the tile reaches past the window
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 w4 = __builtin_bit_cast(u4, o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w4[j] = (p < L) ? w4[j] : 0u;
+                    o = __builtin_bit_cast(bf8, w4);
+                }
+                if (p < P_LMAX + P_HALO) lds_write(img, wa + t * (16 * P_ROW_BYTES), o);
+            };
+            {
+                float sc[8], sh[8];
+                lds8(sc, lc + CST_SCALE + c0);
+                lds8(sh, lc + CST_SHIFT + c0);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = relu1(acc[0][t][j]); v[4 + j] = relu1(acc[1][t][j]); }
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const v2f r2 = __builtin_elementwise_fma((v2f){v[j], v[j + 1]}, (v2f){sc[j], sc[j + 1]}, (v2f){sh[j], sh[j + 1]});
+                        v[j] = r2[0]; v[j + 1] = r2[1];
+                    }
+                    store_tile(dst, t, v);
+                }
+            }
+            {
+                const char* nb = residual ? blk : blk_of(last_layer ? l : l + 1);
+                load_first_r(pre_a, (gbf8r)(nb + (residual ? WP_RES_OFF : WP_CONV_OFF)) + 2 * q * 64 + lane);
+            }
+            if (!last_layer) cst_put(l + 1);
+            PFENCE();
+            RSTAMP(sb + 2);
+            if (defer) bottleneck_r<PT>(src, blk_of(l - 1), a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            RSTAMP(sb + 7);
+            __syncthreads();
+            PFENCE();
+            RSTAMP(sb + 3);
+            if (residual) {
+                {
+                    float br[8];
+                    lds8(br, lc + CST_BRES + c0);
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        const bf8 x = lds_read(src, wa + t * (16 * P_ROW_BYTES));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { acc[0][t][j] = (float)x[j] + br[j]; acc[1][t][j] = (float)x[4 + j] + br[4 + j]; }
+                    }
+                }
+                gbf8r wres = (gbf8r)(blk + WP_RES_OFF) + 2 * q * 64 + lane;
+                PFENCE();
+                gemm_r<PT, 1>(acc, dst, xb1, xb1, xb1, wres, pre_a);
+                PFENCE();
+                RSTAMP(sb + 4);
+                load_first_r(pre_a, (gbf8r)(blk_of(last_layer ? l : l + 1) + WP_CONV_OFF) + 2 * q * 64 + lane);
+                char* back = lds + cur * P_IMG_BYTES;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[0][t][j]; v[4 + j] = acc[1][t][j]; }
+                    store_tile(back, t, v);
+                }
+                __syncthreads();
+                PFENCE();
+                RSTAMP(sb + 5);
+            } else {
+                cur ^= 1;
+            }
+            if (a.tap && a.tap_layer == l + 1) copy_tap(cur, CPAD);
+            if (last_layer) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (resumed && next_row >= 0) { dma_img = cur ^ 1; dma_read(next_row, dma_img, lane); }
+                if (a.has_hw)
+                    bottleneck_r<PT>(lds + cur * P_IMG_BYTES, blk, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            }
+            RSTAMP(sb + 6);
+        }
+        RSTAMP(62);
+        {
+            const char* img = lds + cur * P_IMG_BYTES;
+            bf8* ydst = (bf8*)(a.y + read_idx * (size_t)L * CPAD);
+            constexpr int NC = (P_LMAX * (CPAD / 8) + R_THREADS - 1) / R_THREADS;         // 5
+            bf8 v[NC];
+#pragma unroll
+            for (int k2 = 0; k2 < NC; ++k2) {
+                const int i = tid + k2 * R_THREADS;
+                v[k2] = lds_read(img, cell_addr(P_HALO + min(i >> 4, P_LMAX - 1), i & 15));
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < NC; ++k2) {
+                const int i = tid + k2 * R_THREADS;
+                if (i < L * (CPAD / 8)) ydst[i] = v[k2];
+            }
+        }
+        if (resumed && a.pool && next_row >= 0) seed_request(next_row, lane);
+        RSTAMP(63);
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
 // Staggered form (DAN_BF16_FORM=q; not the default, see launch_segmentp): the two position halves of a read run ONE PHASE APART, so that on every SIMD one wave's MFMA
 // stage (conv / residual GEMM) runs beside the other wave's VALU + LDS stage (epilogue, write-back, copies) instead of both
 // waves computing together and then leaving the matrix pipe idle together (the lockstep form above: ~45 % of a layer).
@@ -862,7 +1248,11 @@ void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t
     // beside 300 / 600 / 1000 vector instructions) -- an epilogue beside a GEMM costs what it costs behind it, and the form pays
     // 20 % of redundant tiles on top.  DESIGN.md section 11.1.
     const char* form_env = getenv("DAN_BF16_FORM");
-    if (staggered_ok(a) && form_env && form_env[0] == 'q')
+    if (a.wlr && form_env && form_env[0] == 'r') {
+        if (a.L <= 4 * 3 * 16) hipLaunchKernelGGL((segmentr_kernel<3>), dim3((unsigned)wgs), dim3(R_THREADS), 0, s, a);
+        else if (a.L <= 4 * 4 * 16) hipLaunchKernelGGL((segmentr_kernel<4>), dim3((unsigned)wgs), dim3(R_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((segmentr_kernel<5>), dim3((unsigned)wgs), dim3(R_THREADS), 0, s, a);
+    } else if (staggered_ok(a) && form_env && form_env[0] == 'q')
         hipLaunchKernelGGL(segmentq_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
     // each position half owns MT tiles of 32 columns: the narrowest tiling that covers the window (201 columns on 2 x 5 tiles
     // would spend 37 % of the MFMAs past column 201; 2 x 4 tiles 22 %)

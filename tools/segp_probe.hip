@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), &d_st, sizeof d_st));
 #endif
     SegmentPArgs a{};
-    a.wl = d_wl; a.l_begin = l_begin; a.l_end = l_end; a.n_layers = layers; a.dil_mid = 2; a.dil_final = 2;
+    a.wl = d_wl; a.wlr = d_wl; a.l_begin = l_begin; a.l_end = l_end; a.n_layers = layers; a.dil_mid = 2; a.dil_final = 2;
     a.res_mask = 0x70; a.has_hw = 1; a.R = R; a.L = L;
     a.reads = a.qual = a.strand = a.ref = a.ref_mask = a.var_mask = d_u8;
     a.emb = d_emb; a.pe = d_pe; a.y = d_y; a.pool = l_begin ? d_pool : nullptr; a.h = d_h; a.h_layer_stride = (long long)hls;
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
         std::sort(d.begin(), d.end());
         return d[d.size() / 2];
     };
-    if (!(getenv("DAN_BF16_FORM") && getenv("DAN_BF16_FORM")[0] == 'p')) {
+    if (!(getenv("DAN_BF16_FORM") && (getenv("DAN_BF16_FORM")[0] == 'p' || getenv("DAN_BF16_FORM")[0] == 'r'))) {
         // staggered form: stamps 0, then (end of stage, start of next stage) pairs around every barrier
         printf("staggered form, segment [%d,%d) L=%d: median cycles per stage of the third row, half 0 | half 1  (stage work, then its barrier wait)\n", l_begin, l_end, L);
         for (int k = 0; k + 2 < 64; k += 2) {
