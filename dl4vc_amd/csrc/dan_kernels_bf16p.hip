@@ -659,6 +659,35 @@ __device__ __forceinline__ void bottleneck_r(const char* img, const char* blk, u
     }
 }
 
+// ... the same with the weights requested by the caller (the deferred bottleneck of the layer before: see the epilogue)
+template <int PT>
+__device__ __forceinline__ void bottleneck_rw(const char* img, const bf8 (&wb)[R_KS][2], v4f bb0, v4f bb1, uint16_t* hrow, int L,
+                                              int wave, int lane) {
+    constexpr int NT = 4 * PT, NTL = (NT + R_WAVES - 1) / R_WAVES;
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+    const unsigned xa0 = cell_addr(P_HALO + n, g);
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int tl = wave + R_WAVES * i;
+        if (tl >= NT) break;
+        const char* tile = img + tl * (16 * P_ROW_BYTES);
+        bf8 bx[R_KS];
+#pragma unroll
+        for (int ks = 0; ks < R_KS; ++ks) bx[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 6));
+        v4f h0 = bb0, h1 = bb1;
+#pragma unroll
+        for (int ks = 0; ks < R_KS; ++ks) { h0 = mfma16r(wb[ks][0], bx[ks], h0); h1 = mfma16r(wb[ks][1], bx[ks], h1); }
+        const int p = 16 * tl + n;
+        if (p < L) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = relu1(h0[j]); v[4 + j] = relu1(h1[j]); }
+            *(bf8*)(hrow + (size_t)p * HPAD + 8 * g) = pack8(v);
+        }
+    }
+}
+
 template <int PT>
 __global__ __launch_bounds__(R_THREADS, 1) void segmentr_kernel(SegmentPArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[P_LDS_BYTES];
@@ -833,12 +862,24 @@ __global__ __launch_bounds__(R_THREADS, 1) void segmentr_kernel(SegmentPArgs a) 
                 }
                 if (p < P_LMAX + P_HALO) lds_write(img, wa + t * (16 * P_ROW_BYTES), o);
             };
+            bf8 wb[R_KS][2];
+            v4f bb0, bb1;
             {
                 float sc[8], sh[8];
                 lds8(sc, lc + CST_SCALE + c0);
                 lds8(sh, lc + CST_SHIFT + c0);
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
+                    // the deferred bottleneck's weights (layer l-1; for the segment's first layer a harmless request of its own):
+                    // requested UNCONDITIONALLY (a conditional definition would keep 32 registers live through the GEMM) and only
+                    // once most accumulators are stored -- beside all of them they do not fit a 128-register wave
+                    if (t == (PT >= 4 ? PT - 2 : PT - 1)) {
+                        gbf8r wbot = (gbf8r)(blk_of(l > a.l_begin ? l - 1 : l) + WP_BOT_OFF) + lane;
+#pragma unroll
+                        for (int ks = 0; ks < R_KS; ++ks) { wb[ks][0] = wbot[(ks * 2) * 64]; wb[ks][1] = wbot[(ks * 2 + 1) * 64]; }
+                        const float* bp = (const float*)(blk_of(l > a.l_begin ? l - 1 : l) + WP_CST_OFF) + CST_BBOT + 8 * g;
+                        bb0 = *(const v4f*)bp; bb1 = *(const v4f*)(bp + 4);
+                    }
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = relu1(acc[0][t][j]); v[4 + j] = relu1(acc[1][t][j]); }
@@ -857,7 +898,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void segmentr_kernel(SegmentPArgs a) 
             if (!last_layer) cst_put(l + 1);
             PFENCE();
             RSTAMP(sb + 2);
-            if (defer) bottleneck_r<PT>(src, blk_of(l - 1), a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            if (defer) bottleneck_rw<PT>(src, wb, bb0, bb1, a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
             RSTAMP(sb + 7);
             __syncthreads();
             PFENCE();
