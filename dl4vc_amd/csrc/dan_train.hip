@@ -944,9 +944,10 @@ void launch_pack_wc(float* dst, const float* src, int H, int L, hipStream_t s) {
 // final max + mean pool backward (dl4vc/model.py:824-839): the max's gradient goes to the FIRST read attaining it
 // (torch's max_pool2d keeps the first index on ties: all-padding rows of a pileup are identical)
 // ------------------------------------------------------------------------------------------------
+template <int PT>       // positions per workgroup: 32, or 8 when 32 would leave most CUs without a workgroup (10 sites: 70 -> 260)
 __global__ __launch_bounds__(256) void final_pool_bwd_kernel(const v4f* __restrict__ y, const float* __restrict__ dfeat, long long fs,
                                                              v4f* __restrict__ g, int R, int L, int C) {
-    constexpr int PT = 32, PS = PT + 1;
+    constexpr int PS = PT + 1;
     __shared__ float dmax[CPAD * PS], dmean[CPAD * PS];
     const int pt = blockIdx.x, site = blockIdx.y, tid = threadIdx.x;
     const float* row = dfeat + (size_t)site * fs;
@@ -986,7 +987,10 @@ __global__ __launch_bounds__(256) void final_pool_bwd_kernel(const v4f* __restri
 }
 
 void launch_final_pool_bwd(const float* y, const float* dfeat, long long fs, float* g, int n_sites, int R, int L, int C, hipStream_t s) {
-    hipLaunchKernelGGL(final_pool_bwd_kernel, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const v4f*)y, dfeat, fs, (v4f*)g, R, L, C);
+    if (((L + 31) / 32) * n_sites >= 512)
+        hipLaunchKernelGGL(final_pool_bwd_kernel<32>, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const v4f*)y, dfeat, fs, (v4f*)g, R, L, C);
+    else
+        hipLaunchKernelGGL(final_pool_bwd_kernel<8>, dim3((L + 7) / 8, n_sites), dim3(256), 0, s, (const v4f*)y, dfeat, fs, (v4f*)g, R, L, C);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1353,7 +1357,7 @@ void launch_gemm(const float* A, long long lda, int a_kslow, const float* B, lon
     const int tiles_m = (M + GM - 1) / GM, tiles_n = (N + GN - 1) / GN, tiles = tiles_m * tiles_n;
     // too few tiles to fill 256 CUs and a long K: split K (deterministic: partials summed in split order)
     int splits = 1;
-    if (split_ws && tiles < 64 && K >= 64 * GK) {
+    if (split_ws && tiles < 64 && K >= 16 * GK) {               // (from K = 512 on: the 10-site step's highway gradients have K = 1000)
         splits = std::min(256 / tiles, K / (8 * GK));
         while (splits > 1 && (long long)splits * M * N > split_ws_floats) --splits;
     }
