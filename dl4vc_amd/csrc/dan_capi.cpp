@@ -57,6 +57,8 @@ struct dan_handle {
     float* d_wc16 = nullptr;                 // compression weights in the channel order of a 16-byte bf16 load of h
     float *d_wpool = nullptr, *d_cols = nullptr, *d_cp = nullptr, *d_zero = nullptr;   // conv(read-mean): weights [segment][128][384], scratch, result
     bool use_p = false;                      // precision 2 on dan_kernels_bf16p.hip: y and h cross HBM as bf16
+    bool use_x = false;                      // precision 1 on dan_kernels_bf16x.hip: y crosses HBM as two bf16 planes (hi, lo)
+    char* d_wlx = nullptr;                   // [layers][WX_LAYER_BYTES] hi / lo 16x16x32 fragments of the bf16x3 kernel
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
@@ -222,6 +224,26 @@ void pack_fragr(uint16_t* dst, int taps, int ksteps, int n_ct, F W) {
             }
 }
 
+// MFMA 16x16x32 bf16 A-fragment order of the bf16x3 kernel (dan_kernels_bf16x.hip): pack_fragr's row order, hi and lo plane of a
+// tile side by side -- fragment ((ks * taps + t) * n_ct + ct) * 2 + plane, lo = bf16(w - hi)
+template <typename F>
+void pack_fragx(uint16_t* dst, int taps, int ksteps, int n_ct, F W) {
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int t = 0; t < taps; ++t)
+            for (int ct = 0; ct < n_ct; ++ct) {
+                uint16_t* f = dst + ((size_t)(ks * taps + t) * n_ct + ct) * 2 * (WP_FRAG / 2);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = lane & 15;
+                        const int o = 32 * (ct >> 1) + 8 * (r >> 2) + 4 * (ct & 1) + (r & 3);
+                        const float w = W(o, 32 * ks + 8 * (lane >> 4) + j, t);
+                        const uint16_t hi = bf16_bits(w);
+                        f[lane * 8 + j] = hi;
+                        f[WP_FRAG / 2 + lane * 8 + j] = bf16_bits(w - bf16_float(hi));
+                    }
+            }
+}
+
 // MFMA 16x16x32 bf16 A-fragment order, hi plane then lo plane (lo = bf16(w - hi)):
 //   plane[((tap*kg + g)*tiles + n)*64 + lane][j] = W[o = 16n + (lane&15)][c = 32g + 8(lane>>4) + j][tap]
 template <typename F>
@@ -367,7 +389,7 @@ int dan_finalize(dan_t* h) {
 
     // ---- conv stack: one fixed-stride weight block per layer (dan_kernels.h)
     std::vector<float> wl((size_t)c.layers * LAYER_STRIDE, 0.f);
-    std::vector<char> wl16(c.precision ? (size_t)c.layers * W16_LAYER_BYTES : 0, 0);
+    std::vector<char> wl16(c.precision ? (size_t)c.layers * W16_LAYER_BYTES : 0, 0);    // (the eight-wave family: fallback forms)
     // precision 2 runs on the ping-pong kernel (bf16 y / h in HBM) unless the structure needs the older forms or
     // DAN_BF16_FORM = 4 | 8 asks for them (A/B runs, the form-vs-form tests)
     {
@@ -377,10 +399,15 @@ int dan_finalize(dan_t* h) {
         for (int l1 = 1; l1 <= c.layers; ++l1) if (is_residual(c, l1)) rm |= 1u << (l1 - 1);
         for (int sg = 0; ok && sg < h->n_segments; ++sg) ok = segmentp_supports(L, h->seg_begin[sg], rm, sg > 0);
         h->use_p = ok;
+        // precision 1 runs on the split kernel of dan_kernels_bf16x.hip (every structure; DAN_BF16_FORM = 8 keeps round 1's kernel
+        // for A/B runs)
+        h->use_x = c.precision == 1 && !(form_env && form_env[0] == '8');
     }
+    const bool conv_pool = h->use_p || h->use_x;                 // the read-mean enters the layer behind it as conv(pool)
     std::vector<char> wlp(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
     std::vector<char> wlr(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
-    std::vector<float> wpool_all(h->use_p ? (size_t)h->n_segments * CPAD * 3 * CPAD : 0, 0.f);
+    std::vector<char> wlx(h->use_x ? (size_t)c.layers * WX_LAYER_BYTES : 0, 0);
+    std::vector<float> wpool_all(conv_pool ? (size_t)h->n_segments * CPAD * 3 * CPAD : 0, 0.f);
     std::vector<float> wc16_all;
     const size_t wc16_layer = (size_t)L * 2 * 2 * 64 * 4;    // floats: [pos][n 2][plane 2][lane 64][8 bf16]
     if (h->use_p && H > 0) wc16_all.resize((size_t)c.layers * wc16_layer);
@@ -430,13 +457,16 @@ int dan_finalize(dan_t* h) {
         if (blkp) pack_fragp((uint16_t*)(blkp + WP_CONV_OFF), 3, l == 0 ? P_KS0 : P_KSC, 4, Wf);
         char* blkr = h->use_p ? wlr.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
         if (blkr) pack_fragr((uint16_t*)(blkr + WP_CONV_OFF), 3, l == 0 ? 2 : 4, 8, Wf);
-        if (blkp && l > 0)
+        char* blkx = h->use_x ? wlx.data() + (size_t)l * WX_LAYER_BYTES : nullptr;
+        if (blkx) pack_fragx((uint16_t*)(blkx + WX_CONV_OFF), 3, l == 0 ? X_KS0 : X_KS, 8, Wf);
+        if (conv_pool && l > 0)
             for (int sg = 1; sg < h->n_segments; ++sg)
-                if (h->seg_begin[sg] == l) {                     // the layer behind a pool layer: its bf16-rounded weights, [o][t * 128 + c]
-                    float* wp = wpool_all.data() + (size_t)sg * CPAD * 3 * CPAD;
+                if (h->seg_begin[sg] == l) {                     // the layer behind a pool layer: its weights, [o][t * 128 + c] -- bf16-rounded for the
+                    float* wp = wpool_all.data() + (size_t)sg * CPAD * 3 * CPAD;   // plain-bf16 kernel (its oracle's "storage" mode), fp32 for bf16x3
                     for (int o = 0; o < CPAD; ++o)
                         for (int t = 0; t < 3; ++t)
-                            for (int cc = 0; cc < CPAD; ++cc) wp[((size_t)o * 3 + t) * CPAD + cc] = bf16_float(bf16_bits(Wf(o, cc, t)));
+                            for (int cc = 0; cc < CPAD; ++cc)
+                                wp[((size_t)o * 3 + t) * CPAD + cc] = h->use_p ? bf16_float(bf16_bits(Wf(o, cc, t))) : Wf(o, cc, t);
                 }
         float* cst = blk + CST_OFF;
         for (int o = 0; o < cout; ++o) { cst[CST_BIAS + o] = b->data[o]; cst[CST_SCALE + o] = 1.f; }
@@ -462,6 +492,7 @@ int dan_finalize(dan_t* h) {
             if (blk16) pack_frag16((uint16_t*)(blk16 + W16_RES_OFF), W16_RES_FRAGS, 1, KG16_C, KGC, Wr);
             if (blkp) pack_fragp((uint16_t*)(blkp + WP_RES_OFF), 1, P_KSC, 4, Wr);
             if (blkr) pack_fragr((uint16_t*)(blkr + WP_RES_OFF), 1, 4, 8, Wr);
+            if (blkx) pack_fragx((uint16_t*)(blkx + WX_RES_OFF), 1, X_KS, 8, Wr);
             for (int o = 0; o < cout; ++o) cst[CST_BRES + o] = br->data[o];
             h->res_mask |= 1u << l;
         }
@@ -475,6 +506,7 @@ int dan_finalize(dan_t* h) {
             if (blk16) pack_frag16((uint16_t*)(blk16 + W16_BOT_OFF), W16_BOT_FRAGS, 1, KG16_C, 2, Wb);
             if (blkp) pack_fragp((uint16_t*)(blkp + WP_BOT_OFF), 1, P_KSC, 1, Wb);
             if (blkr) pack_fragr((uint16_t*)(blkr + WP_BOT_OFF), 1, 4, 2, Wb);
+            if (blkx) pack_fragx((uint16_t*)(blkx + WX_BOT_OFF), 1, X_KS, 2, Wb);
             for (int o = 0; o < H; ++o) cst[CST_BBOT + o] = bb->data[o];
             const std::string z = "conv1D_compression_layers." + std::to_string(l);
             const Tensor* wcm = need(h, z + ".weight", {H, H, 1, L}, &rc); if (!wcm) return rc;
@@ -517,13 +549,19 @@ int dan_finalize(dan_t* h) {
         if ((rc = dev_upload(h, &h->d_wlp, wlp))) return rc;
         if ((rc = dev_upload(h, &h->d_wlr, wlr))) return rc;
         if (H > 0 && (rc = dev_upload(h, &h->d_wc16, wc16_all))) return rc;
-        if (h->n_segments > 1) {
-            if ((rc = dev_upload(h, &h->d_wpool, wpool_all))) return rc;
-            std::vector<float> zeros(CPAD, 0.f);
-            if ((rc = dev_upload(h, &h->d_zero, zeros))) return rc;
-        }
     }
-    if (c.precision) {                                       // constants are shared: copy each layer's fp32 block tail
+    if (h->use_x) {
+        for (int l = 0; l < c.layers; ++l)
+            memcpy(wlx.data() + (size_t)l * WX_LAYER_BYTES + WX_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
+                   CST_FLOATS * sizeof(float));
+        if ((rc = dev_upload(h, &h->d_wlx, wlx))) return rc;
+    }
+    if (conv_pool && h->n_segments > 1) {
+        if ((rc = dev_upload(h, &h->d_wpool, wpool_all))) return rc;
+        std::vector<float> zeros(CPAD, 0.f);
+        if ((rc = dev_upload(h, &h->d_zero, zeros))) return rc;
+    }
+    if (c.precision && !h->use_x) {                          // constants are shared: copy each layer's fp32 block tail
         for (int l = 0; l < c.layers; ++l)
             memcpy(wl16.data() + (size_t)l * W16_LAYER_BYTES + W16_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
                    CST_FLOATS * sizeof(float));
@@ -564,7 +602,7 @@ int dan_finalize(dan_t* h) {
     const size_t read_floats = (size_t)L * CPAD;
     if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats))) return rc;
     if ((rc = dev_alloc(h, &h->d_pool, (size_t)h->chunk * read_floats))) return rc;
-    if (h->use_p && h->n_segments > 1) {
+    if (conv_pool && h->n_segments > 1) {
         if ((rc = dev_alloc(h, &h->d_cp, (size_t)h->chunk * read_floats))) return rc;
         if ((rc = dev_alloc(h, &h->d_cols, (size_t)h->chunk * L * 3 * CPAD))) return rc;
     }
@@ -656,6 +694,15 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (c.precision == 0) {
                     launch_segment(a, ns, h->n_cus, s);
+                } else if (h->use_x) {
+                    SegmentXArgs b{};
+                    b.wl = h->d_wlx; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
+                    b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
+                    b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
+                    b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
+                    b.y = (uint16_t*)h->d_y; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = h->d_h; b.h_layer_stride = a.h_layer_stride;
+                    b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
+                    launch_segmentx(b, ns, h->n_cus, s);
                 } else if (h->use_p) {
                     SegmentPArgs b{};
                     b.wl = h->d_wlp; b.wlr = h->d_wlr; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
@@ -677,8 +724,9 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-                    if (h->use_p) {
-                        launch_read_mean16((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                    if (h->use_p || h->use_x) {
+                        if (h->use_x) launch_read_meanx((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                        else launch_read_mean16((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
                         const int ln = h->seg_begin[sg + 1];                      // 0-based layer behind the pool: its dilation
                         launch_conv_pool(h->d_pool, h->d_wpool + (size_t)(sg + 1) * CPAD * 3 * CPAD, h->d_zero, h->d_cols, h->d_cp, ns, L,
                                          ln + 1 < c.layers ? c.dil_mid : c.dil_final, s);
@@ -690,7 +738,8 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
             float* feat = h->d_feat + (size_t)c0 * h->F_stride;
             EventPair ev{};
             int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-            if (h->use_p) launch_final_pool16((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
+            if (h->use_x) launch_final_poolx((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
+            else if (h->use_p) launch_final_pool16((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             else launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
             HIPCHK(h, hipGetLastError());
@@ -869,6 +918,7 @@ int64_t dan_query(const dan_t* h, const char* what) {
     if (w == "tap_sites") return h->last_chunk_sites;
     if (w == "segments") return h->n_segments;
     if (w == "bf16_pingpong") return h->use_p ? 1 : 0;
+    if (w == "bf16x3_split_kernel") return h->use_x ? 1 : 0;
     if (w == "hidden0_stride") return h->n0_stride;
     return fail(h, DAN_ERR_INVALID_ARG, "dan_query: unknown key '%s'", what);
 }

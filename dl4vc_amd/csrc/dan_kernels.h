@@ -175,6 +175,56 @@ void launch_highway16(const uint16_t* h, long long h_layer_stride, const float* 
                       const float* bc, float* feat, long long feat_stride, int feat_off, int n_sites, int R, int L,
                       int H, int layers, const int* row_src, hipStream_t s);
 
+// ---- bf16x3 "split" kernel (dan_kernels_bf16x.hip; dan_config.precision = 1): every GEMM operand as hi + lo bf16, three
+// v_mfma_f32_16x16x32_bf16 per product (wh xh + wl xh + wh xl), fp32 sums.  One read = TWO XOR-swizzled planes (hi, lo) of ONE
+// image updated in place; y crosses HBM as the same two planes ([row][plane 2][L][128] bf16 -- the resumed segment's image
+// arrives by LDS-DMA and the copy-out is a plain copy), h as fp32.
+constexpr int X_PT = 7;                   // 16-column tiles per wave: wave = (channel quarter, position half), 2 x 7 x 16 = 224 columns
+constexpr int X_COLS = 2 * X_PT * 16;
+constexpr int X_LMAX = MPOS;              // 208 (the 14th tile is a phantom: skipped when L <= 208)
+constexpr int X_ROWS = X_COLS + 2 * P_HALO;
+constexpr int X_PLANE = X_ROWS * P_ROW_BYTES;             // 59 392 B
+constexpr int X_LDS_BYTES = 2 * X_PLANE + 4096;           // + two buffers of per-layer constants = 122 880 B
+constexpr int X_KS = CPAD / 32;           // 4 k-steps of 32 channels
+constexpr int X_KS0 = (CIN0 + 31) / 32;   // 2 for layer 1's 48 encoded channels
+// per-layer weight block (bytes): MFMA 16x16x32 A fragments of 1 KiB ([lane 64][8 bf16]) in the sixteen-wave form's row order
+// (row r of channel tile ct -> channel 32 (ct >> 1) + 8 (r >> 2) + 4 (ct & 1) + (r & 3): a lane's two tiles of a column are 8
+// consecutive channels), hi and lo plane of a tile side by side: fragment ((step * tiles + ct) * 2 + plane)
+//   [WX_CONV_OFF) conv       [step = ks * 3 + tap (12)][ct 8][plane 2]      (layer 1 uses the first 6 steps)
+//   [WX_RES_OFF)  residual   [ks 4][ct 8][plane 2]
+//   [WX_BOT_OFF)  bottleneck [ks 4][ct 2][plane 2]
+//   [WX_CST_OFF)  the fp32 constants of the layer, as in the other families
+constexpr int WX_CONV_OFF = 0;
+constexpr int WX_RES_OFF = WX_CONV_OFF + 3 * X_KS * 8 * 2 * WP_FRAG;     // 196 608
+constexpr int WX_BOT_OFF = WX_RES_OFF + X_KS * 8 * 2 * WP_FRAG;          // 262 144
+constexpr int WX_CST_OFF = WX_BOT_OFF + X_KS * 2 * 2 * WP_FRAG;          // 278 528
+constexpr int WX_LAYER_BYTES = WX_CST_OFF + (CST_FLOATS + 32) * 4;
+
+struct SegmentXArgs {
+    const char* wl;              // [layers][WX_LAYER_BYTES]
+    int l_begin, l_end, n_layers, dil_mid, dil_final;
+    unsigned res_mask;
+    int has_hw;
+    int R, L;
+    const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
+    const float* emb;
+    const float* pe;
+    uint16_t* y;                 // bf16 [row][plane 2][L][CPAD]   in/out
+    const float* pool;           // fp32 [site][L][CPAD]: conv(read-mean) of the segment's first layer (launch_conv_pool), or nullptr
+    float* h;                    // fp32 [layer][row][L][HPAD] or nullptr
+    long long h_layer_stride;    // floats between layers of h
+    float* tap;                  // fp32 [row][L][CPAD] or nullptr
+    int tap_layer;
+    int n_rows, slice_rows;      // filled by the launcher
+    const int* work;
+    const int* work_count;
+};
+void launch_segmentx(const SegmentXArgs& a, int n_sites, int n_cus, hipStream_t s);
+// the two reductions over reads from the two-plane y (value = hi + lo, summed in fp32 in read order)
+void launch_read_meanx(const uint16_t* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s);
+void launch_final_poolx(const uint16_t* y, float* feat, long long feat_stride, int n_sites, int R, int L, int C,
+                        const int* row_src, hipStream_t s);
+
 // Empty-row map: a pileup row whose reads / qual / strand bytes are all zero (padding below the site's coverage) encodes to
 // the same activations as every other such row of its site, through every layer.  row_src[site*R + r] = site*R + (first
 // empty row of the site) for an empty row, site*R + r otherwise; the segment kernels walk only the rows that are their own

@@ -1,0 +1,615 @@
+// bf16x3 ("split bf16") conv-stack segment kernel for gfx950 (dan_config.precision = 1): the throughput mode that stays inside
+// the 1e-4 score bar of the fp32 reference.  dl4vc/model.py:728-778 for one read resident in LDS, on the design of the plain-bf16
+// ping-pong kernel (dan_kernels_bf16p.hip) -- XOR-swizzled unpadded images, persistent XCD-sliced workgroups, LDS-DMA prologue,
+// constants staged a layer ahead, the deferred bottleneck -- with every GEMM operand carried as TWO bf16 (hi = bf16(v),
+// lo = bf16(v - hi): 16 mantissa bits) and a product as three MFMAs, wh xh + wl xh + wh xl, summed in fp32:
+//
+//   * v_mfma_f32_16x16x32_bf16, wave = (channel quarter q = wave & 3) x (position half = wave >> 2): 32 output channels x 7
+//     tiles of 16 columns = 56 accumulator registers; an activation fragment (1 KiB ds_read_b128) feeds four (hi plane) or two
+//     (lo plane) MFMAs, a weight fragment seven;
+//   * ONE image of the read in LDS, two planes (hi, lo) of 232 rows x 256 B, updated IN PLACE: a layer's outputs wait in
+//     registers -- already split and packed -- for the barrier behind the GEMM, are stored, and a second barrier publishes them
+//     (two images of two planes do not fit 160 KiB);
+//   * weight rows permuted on the host so that a lane's 2 x 4 accumulators of a column are 8 CONSECUTIVE channels: the epilogue
+//     is one 16-byte LDS store per tile and plane;
+//   * y crosses HBM as the same two planes ([row][plane][L][128] bf16, the bytes of an fp32 y): the resumed segment's image arrives
+//     by LDS-DMA and the copy-out needs no arithmetic; the read-mean enters the layer behind it as conv(pool), one fp32 GEMM
+//     per site that seeds the accumulators (conv(y + pool) = conv(y) + conv(pool)); h stays fp32 (the highway kernel is shared
+//     with the fp32 path).
+//
+// Numerics: products of bf16 pairs are exact in fp32, sums fp32; dropped: wl xl (2^-18 of a product) and what the two-piece
+// split loses of an operand (2^-17).  Bias / ReLU / BatchNorm / residual add in fp32.  Scores within 1e-4 of the reference
+// (tests/test_hip_bf16.py, all golden cases and layer taps).
+#include "dan_kernels.h"
+
+namespace dan {
+namespace x3 {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) bf8* gbf8;
+
+#define XFENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef DAN_STAMPS
+// diagnostic build only (tools/segx_probe.hip): s_memtime stamps of the THIRD row a workgroup walks, per wave
+__device__ unsigned long long* g_xstamps;
+#define XSTAMP(k_)                                                                                    \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
+        if (lane == 0 && k == jw + 2 * nj && (k_) < 64) g_xstamps[((size_t)blockIdx.x * NWAVE + wave) * 64 + (k_)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define XSTAMP(k) do {} while (0)
+#endif
+
+__device__ __forceinline__ v4f mfma16(bf8 a, bf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// ReLU as one integer maximum on the bit pattern (see dan_kernels_bf16p.hip)
+__device__ __forceinline__ float relu1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+__device__ __forceinline__ bf8 lds_read(const char* lds, unsigned addr) { return *(const bf8*)(lds + addr); }
+__device__ __forceinline__ void lds_write(char* lds, unsigned addr, bf8 v) { *(bf8*)(lds + addr) = v; }
+__device__ __forceinline__ unsigned cell_addr(int row, int chunk) { return (unsigned)row * P_ROW_BYTES + (unsigned)((chunk ^ row) & 15) * 16; }
+__device__ __forceinline__ void lds8(float (&v)[8], const float* p) {
+    const v4f t0 = *(const v4f*)p, t1 = *(const v4f*)(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = t0[j]; v[4 + j] = t1[j]; }
+}
+// 8 fp32 -> hi = bf16(v) (ties to even), lo = bf16(v - hi)
+__device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+}
+// zero the 16 bytes of a lane whose column lies past the window
+__device__ __forceinline__ bf8 keep_if(bf8 o, bool keep) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 w4 = __builtin_bit_cast(u4, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = keep ? w4[j] : 0u;
+    return __builtin_bit_cast(bf8, w4);
+}
+
+// LDS-DMA (see dan_kernels_bf16p.hip::glds16): 64 lanes x 16 bytes from per-lane global addresses to lds_base + 16 * lane
+__device__ __forceinline__ void glds16(const void* src, char* lds_base) {
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// acc[e][t] += W(channel tile 2 q + e) x X(16 columns of tile t) over TAPS x 4 k-steps of 32 channels, three MFMAs per product.
+//   lds:    the hi plane (the lo plane lies X_PLANE bytes on);  xb0..2: this lane's byte address of chunk g = lane >> 4 of its row for
+//           tap t (tile 0); chunk 4 ks + g lies at xb ^ (ks << 6), tile t a further t * 16 rows on.
+//   w:      this wave's first fragment (+ lane); channel-group-major walk (step = ks * TAPS + tap); a step's four fragments
+//           (tile e, plane) = w[(step * 16 + 2 e + plane) * 64].  first[] = steps 0 and 1 (requested a stage ahead by the caller).
+// Weights: three steps in flight per wave (a step is 6 PT MFMAs per wave, two waves per SIMD: ~1.3 k cycles; an L2 round trip
+// ~1.5 k).  Activations: a ring of RING tiles, the read of tile i + RING - 1 rides among the MFMAs of tile i.
+template <int PT, int TAPS>
+__device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8 w,
+                                       const bf8 (&first)[2][4], bool k_short = false) {
+    constexpr int S = TAPS * X_KS, NA = 3, RING = 4, N = S * PT;
+    bf8 a[NA][4], bh[RING], bl[RING];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[0][j] = first[0][j]; a[1][j] = first[1][j]; }
+    if (S > 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[2][j] = w[(size_t)(2 * 16 + j) * 64];
+    }
+    auto xaddr = [&](int i) {
+        const int s = i / PT, t = i % PT;
+        const unsigned xt = (s % TAPS == 0) ? xb0 : (s % TAPS == 1) ? xb1 : xb2;
+        return (xt ^ (unsigned)((s / TAPS) << 6)) + (unsigned)(t * (16 * P_ROW_BYTES));
+    };
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) { bh[i] = lds_read(lds, xaddr(i)); bl[i] = lds_read(lds + X_PLANE, xaddr(i)); }
+    XFENCE();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (TAPS == 3 && s == TAPS * X_KS0) {
+            if (k_short) break;
+            XFENCE();
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int i = s * PT + t, in = i + RING - 1;
+            if (in < N) { bh[in % RING] = lds_read(lds, xaddr(in)); bl[in % RING] = lds_read(lds + X_PLANE, xaddr(in)); }
+            const bf8 xh = bh[i % RING], xl = bl[i % RING];
+            acc[0][t] = mfma16(a[s % NA][0], xh, acc[0][t]);
+            acc[1][t] = mfma16(a[s % NA][2], xh, acc[1][t]);
+            acc[0][t] = mfma16(a[s % NA][1], xh, acc[0][t]);
+            acc[1][t] = mfma16(a[s % NA][3], xh, acc[1][t]);
+            acc[0][t] = mfma16(a[s % NA][0], xl, acc[0][t]);
+            acc[1][t] = mfma16(a[s % NA][2], xl, acc[1][t]);
+        }
+        if (s + NA < S) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[s % NA][j] = w[(size_t)((s + NA) * 16 + j) * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (s * PT + t + RING - 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (s * PT + t + RING - 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (s + NA < S) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    }
+}
+
+__device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[s][j] = w[(size_t)(s * 16 + j) * 64];
+}
+
+// h = relu(Wb y + bb), 128 -> 32 (model.py:774) from the image, 16-column tiles dealt over the eight waves; wb[ks][2 e + plane]:
+// the layer's sixteen weight fragments, bb0 / bb1: this lane's 8 biases (requested by the caller a stage ahead).  fp32 out.
+__device__ __forceinline__ void bottleneck_x(const char* lds, const bf8 (&wb)[X_KS][4], v4f bb0, v4f bb1, float* hrow, int L, int wave,
+                                             int lane) {
+    constexpr int NT = 2 * X_PT, NTL = (NT + NWAVE - 1) / NWAVE;
+    asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop)
+    const int n = lane & 15, g = lane >> 4;
+    const unsigned xa0 = cell_addr(P_HALO + n, g);
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int tl = wave + NWAVE * i;
+        if (tl >= NT || 16 * tl >= L) break;                     // (wave-uniform)
+        const char* tile = lds + tl * (16 * P_ROW_BYTES);
+        bf8 bh[X_KS], bl[X_KS];
+#pragma unroll
+        for (int ks = 0; ks < X_KS; ++ks) {
+            bh[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 6));
+            bl[ks] = lds_read(tile + X_PLANE, xa0 ^ (unsigned)(ks << 6));
+        }
+        v4f h0 = bb0, h1 = bb1;
+#pragma unroll
+        for (int ks = 0; ks < X_KS; ++ks) {
+            h0 = mfma16(wb[ks][0], bh[ks], h0);
+            h1 = mfma16(wb[ks][2], bh[ks], h1);
+            h0 = mfma16(wb[ks][1], bh[ks], h0);
+            h1 = mfma16(wb[ks][3], bh[ks], h1);
+            h0 = mfma16(wb[ks][0], bl[ks], h0);
+            h1 = mfma16(wb[ks][2], bl[ks], h1);
+        }
+        const int p = 16 * tl + n;
+        if (p < L) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h0[j] = relu1(h0[j]); h1[j] = relu1(h1[j]); }
+            float* o = hrow + (size_t)p * HPAD + 8 * g;
+            *(v4f*)o = h0;
+            *(v4f*)(o + 4) = h1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(SegmentXArgs a) {
+    constexpr int PT = X_PT;
+    __shared__ __attribute__((aligned(16))) char lds[X_LDS_BYTES];
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int q = wave & 3, half = wave >> 2;
+    const int L = a.L;
+    const int pbase = half * (PT * 16);
+    // behind the two planes: the per-channel constants (bias, scale, shift, bres: 512 floats) of the current layer and of the
+    // next one, staged a layer ahead
+    auto cbuf = [&](int l) { return (float*)(lds + 2 * X_PLANE + (l & 1) * 2048); };
+
+    // zeroed once: the halo rows and the rows past the window are never written with anything but zeros afterwards
+    for (int i = tid0; i < X_LDS_BYTES / 16; i += SEG_THREADS) *(v4f*)(lds + (size_t)i * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // persistent walk over XCD-contiguous slices of whole sites (see dan_kernels_bf16p.hip)
+    const int n_work = a.work_count ? *a.work_count : a.n_rows;
+    const int slice = a.work_count ? (n_work + 7) / 8 : a.slice_rows;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    auto row_of = [&](int k) {
+        const int wk = xcd * slice + k;
+        if (k >= slice || wk >= n_work) return -1;
+        return a.work_count ? a.work[wk] : wk;
+    };
+    const bool resumed = a.l_begin > 0;
+    const size_t y_row = (size_t)2 * L * CPAD;                  // bf16 elements of one read's two planes
+    // a resumed segment's input: both planes of the read by LDS-DMA (1-KiB pieces of 4 rows; the chunk swizzle goes on the
+    // per-lane SOURCE address, the destination is lane-linear)
+    auto dma_read = [&](int row_index, int lane) {
+        const char* ysrc = (const char*)(a.y + (size_t)row_index * y_row);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const char* src = ysrc + (size_t)pl * L * P_ROW_BYTES;
+            char* img = lds + pl * X_PLANE + P_HALO * P_ROW_BYTES;
+            for (int kb = wave; kb * 4 < L; kb += NWAVE) {
+                const int p = 4 * kb + (lane >> 4), r = P_HALO + p;
+                if (p < L) glds16(src + (size_t)p * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
+            }
+        }
+    };
+    // ... and the seed of its first layer's accumulators: conv(pool) of the read's site (launch_conv_pool, model.py:742)
+    v4f acc[2][PT];
+    auto seed_request = [&](int row_index, int lane) {
+        const int n = lane & 15, g = lane >> 4;
+        const float* cp = a.pool + (size_t)(row_index / a.R) * (size_t)L * CPAD + 32 * q + 8 * g;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int p = pbase + 16 * t + n;
+            if (p < L) { acc[0][t] = *(const v4f*)(cp + (size_t)p * CPAD); acc[1][t] = *(const v4f*)(cp + (size_t)p * CPAD + 4); }
+            else { acc[0][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[1][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+        }
+    };
+    if (resumed) {
+        const int r0 = __builtin_amdgcn_readfirstlane(row_of(jw));
+        if (r0 >= 0) {
+            dma_read(r0, tid0 & 63);
+            if (a.pool) seed_request(r0, tid0 & 63);
+        }
+    }
+
+    for (int k = jw; k < slice; k += nj) {
+        const int row_index = __builtin_amdgcn_readfirstlane(row_of(k));
+        if (row_index < 0) break;
+        const int next_row = __builtin_amdgcn_readfirstlane(row_of(k + nj));
+        // (an opaque copy of the thread index per row: hipcc otherwise forms every per-lane address of the row body ahead of the
+        // row loop and keeps them -- spilled -- through all of it)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int n = lane & 15, g = lane >> 4;
+        const int site = row_index / a.R;
+        const size_t read_idx = (size_t)row_index;
+        auto blk_of = [&](int l) { return a.wl + (size_t)l * WX_LAYER_BYTES; };
+        v4f creq;
+        auto cst_request = [&](int l) { if (tid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WX_CST_OFF) + tid * 4); };
+        auto cst_put = [&](int l) { if (tid < 128) *(v4f*)(cbuf(l) + tid * 4) = creq; };
+        XSTAMP(0);
+        cst_request(a.l_begin);
+        const int c0 = 32 * q + 8 * g;                            // this lane's 8 output channels
+        const int row0 = P_HALO + pbase + n;                      // its row in tile 0
+        const unsigned wa = cell_addr(row0, 4 * q + g);           // its output chunk
+        bf8 pre_a[2][4];
+        load_first(pre_a, (gbf8)(blk_of(a.l_begin) + WX_CONV_OFF) + 4 * q * 64 + lane);
+        if (!resumed) {
+            // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, split into the two planes
+            const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+            int ok_ref = 1, ok_var = 1;
+            for (int p = tid; p < L; p += SEG_THREADS) {
+                const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+                ok_ref &= (rm == 0) || (tok == rm);
+                ok_var &= (vm == 0) || (tok == vm);
+            }
+            // workgroup-wide AND through sixteen flag words in the constants buffer that is not in use at a row's start
+            int* flags = (int*)cbuf(a.l_begin + 1);
+            {
+                const int w_ref = __all(ok_ref), w_var = __all(ok_var);
+                if (lane == 0) { flags[wave] = w_ref; flags[NWAVE + wave] = w_var; }
+            }
+            __syncthreads();
+            int agree_ref = 1, agree_var = 1;
+#pragma unroll
+            for (int w8 = 0; w8 < NWAVE; ++w8) { agree_ref &= flags[w8]; agree_var &= flags[NWAVE + w8]; }
+            for (int p = tid; p < L; p += SEG_THREADS) {
+                const int tok = a.reads[rbase + p], qv = a.qual[rbase + p], st = a.strand[rbase + p];
+                const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+                const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
+                const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
+                const float* pp = a.pe + p * EMBED;
+                float row[64];
+#pragma unroll
+                for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
+                row[40] = (float)qv * 0.01f;
+                row[41] = (float)st * 0.5f;
+                row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
+                row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
+                row[44] = (rm != 0) ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 45; c < 64; ++c) row[c] = 0.f;      // (layer 1's second 32-channel step reads chunks 4..7: 6, 7 as zeros)
+                const int r = P_HALO + p;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = row[c * 8 + j];
+                    bf8 vh, vl;
+                    split8(v, vh, vl);
+                    lds_write(lds, cell_addr(r, c), vh);
+                    lds_write(lds + X_PLANE, cell_addr(r, c), vl);
+                }
+            }
+        }
+        cst_put(a.l_begin);
+        if (resumed) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): this wave's pieces of the DMA'd image have landed
+        __syncthreads();
+        XSTAMP(1);
+
+        auto copy_tap = [&](int nch) {
+            // image -> fp32 [L][CPAD] (debug tap)
+            float* dst = a.tap + read_idx * (size_t)L * CPAD;
+            for (int i = tid; i < L * (CPAD / 8); i += SEG_THREADS) {
+                const int p = i >> 4, c = i & 15;
+                const bf8 vh = lds_read(lds, cell_addr(P_HALO + p, c)), vl = lds_read(lds + X_PLANE, cell_addr(P_HALO + p, c));
+                v4f o0, o1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o0[j] = (c * 8 + j < nch) ? (float)vh[j] + (float)vl[j] : 0.f;
+                    o1[j] = (c * 8 + 4 + j < nch) ? (float)vh[4 + j] + (float)vl[4 + j] : 0.f;
+                }
+                *(v4f*)(dst + (size_t)i * 8) = o0;
+                *(v4f*)(dst + (size_t)i * 8 + 4) = o1;
+            }
+        };
+        if (a.tap && a.tap_layer == 0 && !resumed) copy_tap(CIN0);
+
+        bf8 wb[X_KS][4];
+        v4f bb0, bb1;
+        auto bottleneck_request = [&](int lb) {                  // layer lb's bottleneck weights and this lane's biases
+            gbf8 wbot = (gbf8)(blk_of(lb) + WX_BOT_OFF) + lane;
+#pragma unroll
+            for (int ks = 0; ks < X_KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wb[ks][j] = wbot[(size_t)(ks * 4 + j) * 64];
+            const float* bp = (const float*)(blk_of(lb) + WX_CST_OFF) + CST_BBOT + 8 * g;
+            bb0 = *(const v4f*)bp; bb1 = *(const v4f*)(bp + 4);
+        };
+
+        for (int l = a.l_begin; l < a.l_end; ++l) {
+            const char* blk = blk_of(l);
+            const float* lc = cbuf(l);
+            const bool residual = (a.res_mask >> l) & 1u;
+            const bool last_layer = l + 1 == a.l_end;
+            const bool defer = a.has_hw && l > a.l_begin;          // layer l-1's bottleneck runs behind this layer's GEMM
+            const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
+            [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
+            XSTAMP(sb + 0);
+            XFENCE();
+            if (!last_layer) cst_request(l + 1);
+            {
+                float bias[8];
+                lds8(bias, lc + CST_BIAS + c0);
+                const v4f b0 = {bias[0], bias[1], bias[2], bias[3]}, b1 = {bias[4], bias[5], bias[6], bias[7]};
+                if (l == a.l_begin && resumed && a.pool) {       // seeded with conv(pool) of the site (requested a row ahead)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) { acc[0][t] += b0; acc[1][t] += b1; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) { acc[0][t] = b0; acc[1][t] = b1; }
+                }
+            }
+            const unsigned xb0 = cell_addr(row0 - dil, g), xb1 = cell_addr(row0, g), xb2 = cell_addr(row0 + dil, g);
+            gbf8 wconv = (gbf8)(blk + WX_CONV_OFF) + 4 * q * 64 + lane;
+            gemm_x<PT, 3>(acc, lds, xb0, xb1, xb2, wconv, pre_a, l == 0);
+            XFENCE();
+            XSTAMP(sb + 1);
+
+            // ---- epilogue: ReLU, BatchNorm (folded), columns past the window forced to zero, split; the packed outputs wait in
+            // registers for the barrier (the image is updated in place)
+            bf8 oh[PT], ol[PT];
+            auto pack_tile = [&](int t, const float (&v)[8]) {
+                split8(v, oh[t], ol[t]);
+                if (pbase + 16 * t + 16 > L) {                    // (uniform) the tile reaches past the window
+                    const bool keep = pbase + 16 * t + n < L;
+                    oh[t] = keep_if(oh[t], keep);
+                    ol[t] = keep_if(ol[t], keep);
+                }
+            };
+            auto store_tiles = [&]() {
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    lds_write(lds, wa + t * (16 * P_ROW_BYTES), oh[t]);
+                    lds_write(lds + X_PLANE, wa + t * (16 * P_ROW_BYTES), ol[t]);
+                }
+            };
+            if (defer) bottleneck_request(l - 1);
+            else if (a.has_hw && last_layer && !residual) bottleneck_request(l);
+            {
+                float sc[8], sh[8];
+                lds8(sc, lc + CST_SCALE + c0);
+                lds8(sh, lc + CST_SHIFT + c0);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = relu1(acc[0][t][j]); v[4 + j] = relu1(acc[1][t][j]); }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(v[j], sc[j], sh[j]);
+                    pack_tile(t, v);
+                }
+            }
+            // the first fragments of the next GEMM (this layer's residual 1x1, else the next layer's conv) ride under the barrier wait
+            {
+                const char* nb = residual ? blk : blk_of(last_layer ? l : l + 1);
+                load_first(pre_a, (gbf8)(nb + (residual ? WX_RES_OFF : WX_CONV_OFF)) + 4 * q * 64 + lane);
+            }
+            if (!last_layer) cst_put(l + 1);
+            XFENCE();
+            XSTAMP(sb + 2);
+            // ---- layer l-1's bottleneck, from the image this layer's GEMM has just read (intact until the barrier below)
+            if (defer) {
+                bottleneck_x(lds, wb, bb0, bb1, a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+                if (a.has_hw && last_layer && !residual) bottleneck_request(l);
+            }
+            XSTAMP(sb + 7);
+            __syncthreads();                                     // every read of the layer input is done
+            XFENCE();
+            XSTAMP(sb + 3);
+            if (residual) {
+                // y = Wr t + bres + x   (model.py:753-761): x = this lane's own cells of the layer input, replaced by t = the outputs held
+                {
+                    float br[8];
+                    lds8(br, lc + CST_BRES + c0);
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        const bf8 xh = lds_read(lds, wa + t * (16 * P_ROW_BYTES)), xl = lds_read(lds + X_PLANE, wa + t * (16 * P_ROW_BYTES));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[0][t][j] = ((float)xh[j] + (float)xl[j]) + br[j];
+                            acc[1][t][j] = ((float)xh[4 + j] + (float)xl[4 + j]) + br[4 + j];
+                        }
+                    }
+                }
+                store_tiles();
+                __syncthreads();
+                XFENCE();
+                gbf8 wres = (gbf8)(blk + WX_RES_OFF) + 4 * q * 64 + lane;
+                gemm_x<PT, 1>(acc, lds, xb1, xb1, xb1, wres, pre_a);
+                XFENCE();
+                XSTAMP(sb + 4);
+                load_first(pre_a, (gbf8)(blk_of(last_layer ? l : l + 1) + WX_CONV_OFF) + 4 * q * 64 + lane);
+                if (a.has_hw && last_layer) bottleneck_request(l);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[0][t][j]; v[4 + j] = acc[1][t][j]; }
+                    pack_tile(t, v);
+                }
+                __syncthreads();                                 // every read of t is done
+                XFENCE();
+            }
+            store_tiles();
+            __syncthreads();
+            XFENCE();
+            XSTAMP(sb + 5);
+            if (a.tap && a.tap_layer == l + 1) copy_tap(CPAD);
+            if (last_layer && a.has_hw)
+                bottleneck_x(lds, wb, bb0, bb1, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            XSTAMP(sb + 6);
+        }
+        XSTAMP(62);
+        // ---- the segment's output -> y (both planes); every chunk of the thread is read before the image is handed to the next
+        // row's DMA
+        {
+            bf8* ydst = (bf8*)(a.y + read_idx * y_row);
+            constexpr int NC = (2 * X_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;     // 13
+            const int n8 = L * (CPAD / 8);
+            bf8 v[NC];
+#pragma unroll
+            for (int k2 = 0; k2 < NC; ++k2) {
+                const int i = tid + k2 * SEG_THREADS;
+                const int pl = i >= n8 ? 1 : 0, ii = min(i - pl * n8, n8 - 1);
+                v[k2] = lds_read(lds + pl * X_PLANE, cell_addr(P_HALO + (ii >> 4), ii & 15));
+            }
+            __syncthreads();                                     // every read of the image is done: the next row may land in it
+            if (resumed && next_row >= 0) dma_read(next_row, lane);
+#pragma unroll
+            for (int k2 = 0; k2 < NC; ++k2) {
+                const int i = tid + k2 * SEG_THREADS;
+                if (i < 2 * n8) ydst[i] = v[k2];
+            }
+        }
+        if (resumed && a.pool && next_row >= 0) seed_request(next_row, lane);
+        XSTAMP(63);
+    }
+}
+
+}  // namespace x3
+
+void launch_segmentx(const SegmentXArgs& a0, int n_sites, int n_cus, hipStream_t s) {
+    SegmentXArgs a = a0;
+    a.n_rows = n_sites * a.R;
+    a.slice_rows = (n_sites + 7) / 8 * a.R;
+    int wgs = n_cus > 0 ? n_cus : 256;
+    wgs = (wgs + 7) / 8 * 8;
+    const int need = (a.slice_rows < 1 ? 1 : a.slice_rows) * 8;   // no more workgroups than rows per slice x 8
+    if (wgs > need) wgs = need;
+    hipLaunchKernelGGL(x3::segmentx_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The two reductions over reads from the two-plane y: value = hi + lo (exact in fp32), fp32 sums in read order, as the fp32 forms
+// ------------------------------------------------------------------------------------------------
+namespace x3 {
+
+__global__ __launch_bounds__(256) void read_meanx_kernel(const bf8* __restrict__ y, v4f* __restrict__ pool, int R, int L,
+                                                         const int* __restrict__ row_src) {
+    const int n8 = L * (CPAD / 8);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int site = blockIdx.y;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int* rs = row_src ? row_src + (size_t)site * R : nullptr;
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+        const bf8* row = y + (size_t)(rs ? rs[r] : site * R + r) * (2 * n8);
+        const bf8 vh = row[i], vl = row[n8 + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += (float)vh[j] + (float)vl[j];
+    }
+    v4f o0, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o0[j] = sum[j] / (float)R; o1[j] = sum[4 + j] / (float)R; }
+    pool[((size_t)site * n8 + i) * 2] = o0;
+    pool[((size_t)site * n8 + i) * 2 + 1] = o1;
+}
+
+__global__ __launch_bounds__(256) void final_poolx_kernel(const bf8* __restrict__ y, float* __restrict__ feat, long long fs,
+                                                          int R, int L, int C, const int* __restrict__ row_src) {
+    constexpr int PT = 32, PS = PT + 1;                        // 32 positions per workgroup: 128-byte runs in the feature row
+    __shared__ float tmax[CPAD * PS], tavg[CPAD * PS];
+    const int pt = blockIdx.x, site = blockIdx.y, tid = threadIdx.x;
+    const int c8 = tid & 15, pl = tid >> 4;
+    const int n8 = L * (CPAD / 8);
+#pragma unroll
+    for (int pass = 0; pass < PT / 16; ++pass) {
+        const int pp = pass * 16 + pl, p = pt * PT + pp;
+        float mx[8], sum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mx[j] = 0.f; sum[j] = 0.f; }
+        if (p < L) {
+            const size_t off = (size_t)p * (CPAD / 8) + c8;
+            const int* rs = row_src ? row_src + (size_t)site * R : nullptr;
+            auto rowp = [&](int r) { return y + (size_t)(rs ? rs[r] : site * R + r) * (2 * n8) + off; };
+            {
+                const bf8* r0 = rowp(0);
+                const bf8 vh = r0[0], vl = r0[n8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { mx[j] = (float)vh[j] + (float)vl[j]; sum[j] = mx[j]; }
+            }
+#pragma unroll 4
+            for (int r = 1; r < R; ++r) {
+                const bf8* rp = rowp(r);
+                const bf8 vh = rp[0], vl = rp[n8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)vh[j] + (float)vl[j]; mx[j] = fmaxf(mx[j], f); sum[j] += f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] = sum[j] / (float)R;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            tmax[(c8 * 8 + j) * PS + pp] = mx[j];
+            tavg[(c8 * 8 + j) * PS + pp] = sum[j];
+        }
+    }
+    __syncthreads();
+    float* row = feat + (size_t)site * fs;
+    for (int idx = tid; idx < CPAD * PT; idx += 256) {
+        const int c = idx / PT, pp = idx % PT, p = pt * PT + pp;
+        if (c < C && p < L) {
+            row[(size_t)c * L + p] = tmax[c * PS + pp];                         // max block first (model.py:833)
+            row[(size_t)C * L + (size_t)c * L + p] = tavg[c * PS + pp];
+        }
+    }
+}
+
+}  // namespace x3
+
+void launch_read_meanx(const uint16_t* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s) {
+    const int n8 = L * (CPAD / 8);
+    hipLaunchKernelGGL(x3::read_meanx_kernel, dim3((n8 + 255) / 256, n_sites), dim3(256), 0, s, (const x3::bf8*)y, (x3::v4f*)pool, R, L,
+                       row_src);
+}
+
+void launch_final_poolx(const uint16_t* y, float* feat, long long fs, int n_sites, int R, int L, int C, const int* row_src,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(x3::final_poolx_kernel, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const x3::bf8*)y, feat, fs, R, L, C, row_src);
+}
+
+}  // namespace dan
