@@ -399,6 +399,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     n_launch, seg_ms = net.handle.kernel_stats("conv_segment")
+    # the kernel groups behind the dominant one (HIP events, same stream): milliseconds per step
+    other_ms = {k: round(net.handle.kernel_stats(k)[1] / args.steps, 3) for k in ("pool", "highway", "fc", "row_map")}
     net.handle.profile(False)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -523,6 +525,8 @@ def main():
         # whole-forward rate against the direct-convolution MFMA ceiling of the precision, for both definitions of the metric
         ceil_sites = peak * 1e12 / cfg.flops_per_site()
         line["roofline"]["whole_forward_frac"] = round(value / world / ceil_sites, 4)
+        line["roofline"]["other_kernels_ms_per_step"] = other_ms
+        line["roofline"]["kernel_ms_per_step"] = round(seg_ms / args.steps, 3)
         if host_path is not None:
             host_path["ratio_to_value"] = round(host_path["value"] / value, 4)
             line["host_path"] = host_path

@@ -702,6 +702,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
                     b.y = (uint16_t*)h->d_y; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = h->d_h; b.h_layer_stride = a.h_layer_stride;
                     b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
+                    { const char* e = getenv("DAN_X_STAGGER"); b.stagger = e ? atoi(e) : -1; }   // (A/B switch while the kernel is tuned)
                     launch_segmentx(b, ns, h->n_cus, s);
                 } else if (h->use_p) {
                     SegmentPArgs b{};

@@ -183,8 +183,10 @@ constexpr int X_PT = 7;                   // 16-column tiles per wave: wave = (c
 constexpr int X_COLS = 2 * X_PT * 16;
 constexpr int X_LMAX = MPOS;              // 208 (the 14th tile is a phantom: skipped when L <= 208)
 constexpr int X_ROWS = X_COLS + 2 * P_HALO;
-constexpr int X_PLANE = X_ROWS * P_ROW_BYTES;             // 59 392 B
-constexpr int X_LDS_BYTES = 2 * X_PLANE + 4096;           // + two buffers of per-layer constants = 122 880 B
+constexpr int X_ROW_BYTES = 2 * P_ROW_BYTES;              // one image row: the hi plane's 16 chunks, then the lo plane's
+constexpr int X_LO = P_ROW_BYTES;
+constexpr int X_IMG_BYTES = X_ROWS * X_ROW_BYTES;         // 118 784 B
+constexpr int X_LDS_BYTES = X_IMG_BYTES + 4096;           // + two buffers of per-layer constants = 122 880 B
 constexpr int X_KS = CPAD / 32;           // 4 k-steps of 32 channels
 constexpr int X_KS0 = (CIN0 + 31) / 32;   // 2 for layer 1's 48 encoded channels
 // per-layer weight block (bytes): MFMA 16x16x32 A fragments of 1 KiB ([lane 64][8 bf16]) in the sixteen-wave form's row order
@@ -216,6 +218,7 @@ struct SegmentXArgs {
     float* tap;                  // fp32 [row][L][CPAD] or nullptr
     int tap_layer;
     int n_rows, slice_rows;      // filled by the launcher
+    int stagger;                 // filled by the launcher: start offset per workgroup index, in units of 256 cycles
     const int* work;
     const int* work_count;
 };

@@ -55,7 +55,8 @@ __device__ __forceinline__ float relu1(float v) {
 }
 __device__ __forceinline__ bf8 lds_read(const char* lds, unsigned addr) { return *(const bf8*)(lds + addr); }
 __device__ __forceinline__ void lds_write(char* lds, unsigned addr, bf8 v) { *(bf8*)(lds + addr) = v; }
-__device__ __forceinline__ unsigned cell_addr(int row, int chunk) { return (unsigned)row * P_ROW_BYTES + (unsigned)((chunk ^ row) & 15) * 16; }
+// one image row = 512 B: the hi plane's 16 chunks, then the lo plane's (X_LO bytes on); chunk c of row r is stored at c ^ (r & 15)
+__device__ __forceinline__ unsigned cell_addr(int row, int chunk) { return (unsigned)row * X_ROW_BYTES + (unsigned)((chunk ^ row) & 15) * 16; }
 __device__ __forceinline__ void lds8(float (&v)[8], const float* p) {
     const v4f t0 = *(const v4f*)p, t1 = *(const v4f*)(p + 4);
 #pragma unroll
@@ -87,12 +88,15 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_base) {
 }
 
 // acc[e][t] += W(channel tile 2 q + e) x X(16 columns of tile t) over TAPS x 4 k-steps of 32 channels, three MFMAs per product.
-//   lds:    the hi plane (the lo plane lies X_PLANE bytes on);  xb0..2: this lane's byte address of chunk g = lane >> 4 of its row for
-//           tap t (tile 0); chunk 4 ks + g lies at xb ^ (ks << 6), tile t a further t * 16 rows on.
+//   lds:    the image (a row = hi chunks, then lo chunks X_LO bytes on);  xb0..2: this lane's byte address of chunk g = lane >> 4 of
+//           its row for tap t (tile 0); chunk 4 ks + g lies at xb ^ (ks << 6), tile t a further t * 16 rows on.
 //   w:      this wave's first fragment (+ lane); channel-group-major walk (step = ks * TAPS + tap); a step's four fragments
 //           (tile e, plane) = w[(step * 16 + 2 e + plane) * 64].  first[] = steps 0 and 1 (requested a stage ahead by the caller).
 // Weights: three steps in flight per wave (a step is 6 PT MFMAs per wave, two waves per SIMD: ~1.3 k cycles; an L2 round trip
 // ~1.5 k).  Activations: a ring of RING tiles, the read of tile i + RING - 1 rides among the MFMAs of tile i.
+// (Tried: the previous layer's bottleneck folded into this walk -- its B operands ARE the centre tap's fragments.  The units
+// cannot be dealt evenly over four waves with one code path; per-tile tests of the wave's share cut the steps into blocks that
+// hipcc schedules one by one, per-wave copies of the whole walk tripled the spills: 18 k -> 23 k cycles per layer either way.)
 template <int PT, int TAPS>
 __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8 w,
                                        const bf8 (&first)[2][4], bool k_short = false) {
@@ -107,10 +111,10 @@ __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsig
     auto xaddr = [&](int i) {
         const int s = i / PT, t = i % PT;
         const unsigned xt = (s % TAPS == 0) ? xb0 : (s % TAPS == 1) ? xb1 : xb2;
-        return (xt ^ (unsigned)((s / TAPS) << 6)) + (unsigned)(t * (16 * P_ROW_BYTES));
+        return (xt ^ (unsigned)((s / TAPS) << 6)) + (unsigned)(t * (16 * X_ROW_BYTES));
     };
 #pragma unroll
-    for (int i = 0; i < RING - 1; ++i) { bh[i] = lds_read(lds, xaddr(i)); bl[i] = lds_read(lds + X_PLANE, xaddr(i)); }
+    for (int i = 0; i < RING - 1; ++i) { bh[i] = lds_read(lds, xaddr(i)); bl[i] = lds_read(lds + X_LO, xaddr(i)); }
     XFENCE();
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -121,7 +125,7 @@ __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsig
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const int i = s * PT + t, in = i + RING - 1;
-            if (in < N) { bh[in % RING] = lds_read(lds, xaddr(in)); bl[in % RING] = lds_read(lds + X_PLANE, xaddr(in)); }
+            if (in < N) { bh[in % RING] = lds_read(lds, xaddr(in)); bl[in % RING] = lds_read(lds + X_LO, xaddr(in)); }
             const bf8 xh = bh[i % RING], xl = bl[i % RING];
             acc[0][t] = mfma16(a[s % NA][0], xh, acc[0][t]);
             acc[1][t] = mfma16(a[s % NA][2], xh, acc[1][t]);
@@ -152,37 +156,55 @@ __device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
         for (int j = 0; j < 4; ++j) f[s][j] = w[(size_t)(s * 16 + j) * 64];
 }
 
-// h = relu(Wb y + bb), 128 -> 32 (model.py:774) from the image, 16-column tiles dealt over the eight waves; wb[ks][2 e + plane]:
-// the layer's sixteen weight fragments, bb0 / bb1: this lane's 8 biases (requested by the caller a stage ahead).  fp32 out.
-__device__ __forceinline__ void bottleneck_x(const char* lds, const bf8 (&wb)[X_KS][4], v4f bb0, v4f bb1, float* hrow, int L, int wave,
-                                             int lane) {
-    constexpr int NT = 2 * X_PT, NTL = (NT + NWAVE - 1) / NWAVE;
+// h = relu(Wb y + bb), 128 -> 32 (model.py:774) from the image, 16-column tiles dealt over waves 0 .. NW-1.  fp32 out.
+//   wbot: the layer's bottleneck fragments (+ lane), (ks, 2 e + plane) = wbot[(ks * 4 + ..) * 64];  bbp: its 32 biases.
+// Channel-group major: the four weight fragments of a group are held for all of the wave's tiles (two groups in flight: 32
+// registers, not the 64 of the whole matrix), the activation fragments of the next (group, tile) are requested under the MFMAs of
+// the current one.  A tile index past the image is clamped (the wave recomputes its last tile; nothing is stored twice).
+// NW = 8: a stage of its own.  NW = 4: the deferred form -- the SIMD arbiter serves the older wave first, so waves 0-3 leave the
+// conv GEMM ~7 k cycles before waves 4-7 and would wait at the barrier: they run the PREVIOUS layer's bottleneck in that wait,
+// from the image the GEMM has just read (as the fp32 kernel does).
+template <int NW>
+__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane) {
+    constexpr int NT = 2 * X_PT, NTL = (NT + NW - 1) / NW, N = X_KS * NTL;
     asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop)
     const int n = lane & 15, g = lane >> 4;
     const unsigned xa0 = cell_addr(P_HALO + n, g);
+    const int nt_live = min(NT, (L + 15) >> 4);                  // tiles that hold window columns
+    bf8 a[2][4], bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[0][j] = wbot[(size_t)j * 64];
+    const v4f bb0 = *(const v4f*)(bbp + 8 * g), bb1 = *(const v4f*)(bbp + 8 * g + 4);
+    v4f h[NTL][2];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) { h[i][0] = bb0; h[i][1] = bb1; }
+    auto xaddr = [&](int k) {                                    // k = ks * NTL + i
+        const int ks = k / NTL, i = k % NTL;
+        const int tl = min(wave + NW * i, nt_live - 1);
+        return (unsigned)(tl * (16 * X_ROW_BYTES)) + (xa0 ^ (unsigned)(ks << 6));
+    };
+    bh[0] = lds_read(lds, xaddr(0)); bl[0] = lds_read(lds + X_LO, xaddr(0));
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int ks = k / NTL, i = k % NTL;
+        if (i == 0 && ks + 1 < X_KS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[(ks + 1) & 1][j] = wbot[(size_t)((ks + 1) * 4 + j) * 64];
+        }
+        if (k + 1 < N) { bh[(k + 1) & 1] = lds_read(lds, xaddr(k + 1)); bl[(k + 1) & 1] = lds_read(lds + X_LO, xaddr(k + 1)); }
+        const bf8 xh = bh[k & 1], xl = bl[k & 1];
+        h[i][0] = mfma16(a[ks & 1][0], xh, h[i][0]);
+        h[i][1] = mfma16(a[ks & 1][2], xh, h[i][1]);
+        h[i][0] = mfma16(a[ks & 1][1], xh, h[i][0]);
+        h[i][1] = mfma16(a[ks & 1][3], xh, h[i][1]);
+        h[i][0] = mfma16(a[ks & 1][0], xl, h[i][0]);
+        h[i][1] = mfma16(a[ks & 1][2], xl, h[i][1]);
+    }
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
-        const int tl = wave + NWAVE * i;
-        if (tl >= NT || 16 * tl >= L) break;                     // (wave-uniform)
-        const char* tile = lds + tl * (16 * P_ROW_BYTES);
-        bf8 bh[X_KS], bl[X_KS];
-#pragma unroll
-        for (int ks = 0; ks < X_KS; ++ks) {
-            bh[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 6));
-            bl[ks] = lds_read(tile + X_PLANE, xa0 ^ (unsigned)(ks << 6));
-        }
-        v4f h0 = bb0, h1 = bb1;
-#pragma unroll
-        for (int ks = 0; ks < X_KS; ++ks) {
-            h0 = mfma16(wb[ks][0], bh[ks], h0);
-            h1 = mfma16(wb[ks][2], bh[ks], h1);
-            h0 = mfma16(wb[ks][1], bh[ks], h0);
-            h1 = mfma16(wb[ks][3], bh[ks], h1);
-            h0 = mfma16(wb[ks][0], bl[ks], h0);
-            h1 = mfma16(wb[ks][2], bl[ks], h1);
-        }
-        const int p = 16 * tl + n;
-        if (p < L) {
+        const int tl = wave + NW * i, p = 16 * tl + n;
+        if (tl < NT && p < L) {
+            v4f h0 = h[i][0], h1 = h[i][1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { h0[j] = relu1(h0[j]); h1[j] = relu1(h1[j]); }
             float* o = hrow + (size_t)p * HPAD + 8 * g;
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
     const int pbase = half * (PT * 16);
     // behind the two planes: the per-channel constants (bias, scale, shift, bres: 512 floats) of the current layer and of the
     // next one, staged a layer ahead
-    auto cbuf = [&](int l) { return (float*)(lds + 2 * X_PLANE + (l & 1) * 2048); };
+    auto cbuf = [&](int l) { return (float*)(lds + X_IMG_BYTES + (l & 1) * 2048); };
 
     // zeroed once: the halo rows and the rows past the window are never written with anything but zeros afterwards
     for (int i = tid0; i < X_LDS_BYTES / 16; i += SEG_THREADS) *(v4f*)(lds + (size_t)i * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -223,14 +245,12 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
     // per-lane SOURCE address, the destination is lane-linear)
     auto dma_read = [&](int row_index, int lane) {
         const char* ysrc = (const char*)(a.y + (size_t)row_index * y_row);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const char* src = ysrc + (size_t)pl * L * P_ROW_BYTES;
-            char* img = lds + pl * X_PLANE + P_HALO * P_ROW_BYTES;
-            for (int kb = wave; kb * 4 < L; kb += NWAVE) {
-                const int p = 4 * kb + (lane >> 4), r = P_HALO + p;
-                if (p < L) glds16(src + (size_t)p * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
-            }
+        char* img = lds + P_HALO * X_ROW_BYTES;
+        // a 1-KiB piece = two image rows: lane -> row 2 kb + (lane >> 5), plane (lane >> 4) & 1, stored chunk lane & 15
+        const int pl = (lane >> 4) & 1;
+        for (int kb = wave; kb * 2 < L; kb += NWAVE) {
+            const int p = 2 * kb + (lane >> 5), r = P_HALO + p;
+            if (p < L) glds16(ysrc + ((size_t)pl * L + p) * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
         }
     };
     // ... and the seed of its first layer's accumulators: conv(pool) of the read's site (launch_conv_pool, model.py:742)
@@ -245,13 +265,40 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             else { acc[0][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[1][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
         }
     };
-    if (resumed) {
+    auto blk_of = [&](int l) { return a.wl + (size_t)l * WX_LAYER_BYTES; };
+    // What a row needs from global memory at its start is requested a row AHEAD, in front of the previous row's copy-out stores
+    // (vector-memory operations of a wave retire in order: a load behind 13 stores waits for them): the first layer's constants
+    // and first weight fragments (the same for every row), the row's token bytes (encode) or image + accumulator seed (resumed)
+    v4f creq;
+    bf8 pre_a[2][4];
+    int tk_tok = 0, tk_q = 0, tk_st = 0, tk_rf = 0, tk_rm = 0, tk_vm = 0;
+    auto cst_request = [&](int l, int tid) { if (tid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WX_CST_OFF) + tid * 4); };
+    auto first_request = [&](int tid) {                          // the segment's first layer, for the next row
+        cst_request(a.l_begin, tid);
+        load_first(pre_a, (gbf8)(blk_of(a.l_begin) + WX_CONV_OFF) + 4 * q * 64 + (tid & 63));
+    };
+    auto token_request = [&](int row_index, int tid) {           // one window column per thread (L <= 208 < 512)
+        if (tid < L) {
+            const size_t rb = (size_t)row_index * L + tid, sbs = (size_t)(row_index / a.R) * L + tid;
+            tk_tok = a.reads[rb]; tk_q = a.qual[rb]; tk_st = a.strand[rb];
+            tk_rf = a.ref[sbs]; tk_rm = a.ref_mask[sbs]; tk_vm = a.var_mask[sbs];
+        }
+    };
+    {
         const int r0 = __builtin_amdgcn_readfirstlane(row_of(jw));
         if (r0 >= 0) {
-            dma_read(r0, tid0 & 63);
-            if (a.pool) seed_request(r0, tid0 & 63);
+            first_request(tid0);
+            if (resumed) {
+                dma_read(r0, tid0 & 63);
+                if (a.pool) seed_request(r0, tid0 & 63);
+            } else {
+                token_request(r0, tid0);
+            }
         }
     }
+    // every workgroup of a launch has the same work per row: left alone they stay in step and take turns at HBM in bursts (all
+    // 256 copy-outs, then all 256 image loads).  A start offset of stagger x 256 cycles per workgroup spreads the phases.
+    for (int i = 0; i < (int)blockIdx.x * a.stagger; ++i) __builtin_amdgcn_s_sleep(4);
 
     for (int k = jw; k < slice; k += nj) {
         const int row_index = __builtin_amdgcn_readfirstlane(row_of(k));
@@ -263,28 +310,17 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63;
         const int n = lane & 15, g = lane >> 4;
-        const int site = row_index / a.R;
         const size_t read_idx = (size_t)row_index;
-        auto blk_of = [&](int l) { return a.wl + (size_t)l * WX_LAYER_BYTES; };
-        v4f creq;
-        auto cst_request = [&](int l) { if (tid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WX_CST_OFF) + tid * 4); };
         auto cst_put = [&](int l) { if (tid < 128) *(v4f*)(cbuf(l) + tid * 4) = creq; };
         XSTAMP(0);
-        cst_request(a.l_begin);
         const int c0 = 32 * q + 8 * g;                            // this lane's 8 output channels
         const int row0 = P_HALO + pbase + n;                      // its row in tile 0
         const unsigned wa = cell_addr(row0, 4 * q + g);           // its output chunk
-        bf8 pre_a[2][4];
-        load_first(pre_a, (gbf8)(blk_of(a.l_begin) + WX_CONV_OFF) + 4 * q * 64 + lane);
         if (!resumed) {
-            // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, split into the two planes
-            const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
-            int ok_ref = 1, ok_var = 1;
-            for (int p = tid; p < L; p += SEG_THREADS) {
-                const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
-                ok_ref &= (rm == 0) || (tok == rm);
-                ok_var &= (vm == 0) || (tok == vm);
-            }
+            // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, split into the two planes; thread p = column p
+            const int tok = tk_tok, qv = tk_q, st = tk_st, rf = tk_rf, rm = tk_rm, vm = tk_vm;
+            const bool col = tid < L;
+            const int ok_ref = !col || (rm == 0) || (tok == rm), ok_var = !col || (vm == 0) || (tok == vm);
             // workgroup-wide AND through sixteen flag words in the constants buffer that is not in use at a row's start
             int* flags = (int*)cbuf(a.l_begin + 1);
             {
@@ -295,9 +331,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             int agree_ref = 1, agree_var = 1;
 #pragma unroll
             for (int w8 = 0; w8 < NWAVE; ++w8) { agree_ref &= flags[w8]; agree_var &= flags[NWAVE + w8]; }
-            for (int p = tid; p < L; p += SEG_THREADS) {
-                const int tok = a.reads[rbase + p], qv = a.qual[rbase + p], st = a.strand[rbase + p];
-                const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
+            if (col) {
+                const int p = tid;
                 const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
                 const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
                 const float* pp = a.pe + p * EMBED;
@@ -320,12 +355,17 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                     bf8 vh, vl;
                     split8(v, vh, vl);
                     lds_write(lds, cell_addr(r, c), vh);
-                    lds_write(lds + X_PLANE, cell_addr(r, c), vl);
+                    lds_write(lds + X_LO, cell_addr(r, c), vl);
                 }
             }
         }
         cst_put(a.l_begin);
-        if (resumed) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): this wave's pieces of the DMA'd image have landed
+        if (resumed) {
+            // this wave's pieces of the DMA'd image have landed.  Behind them in the queue are only the previous row's copy-out stores
+            // (at least L / 16 per wave): they may stay in flight
+            if (L >= 192) __builtin_amdgcn_s_waitcnt(0x0F70 | 12);   // vmcnt(12)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+        }
         __syncthreads();
         XSTAMP(1);
 
@@ -334,7 +374,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             float* dst = a.tap + read_idx * (size_t)L * CPAD;
             for (int i = tid; i < L * (CPAD / 8); i += SEG_THREADS) {
                 const int p = i >> 4, c = i & 15;
-                const bf8 vh = lds_read(lds, cell_addr(P_HALO + p, c)), vl = lds_read(lds + X_PLANE, cell_addr(P_HALO + p, c));
+                const bf8 vh = lds_read(lds, cell_addr(P_HALO + p, c)), vl = lds_read(lds + X_LO, cell_addr(P_HALO + p, c));
                 v4f o0, o1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -347,29 +387,19 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
         };
         if (a.tap && a.tap_layer == 0 && !resumed) copy_tap(CIN0);
 
-        bf8 wb[X_KS][4];
-        v4f bb0, bb1;
-        auto bottleneck_request = [&](int lb) {                  // layer lb's bottleneck weights and this lane's biases
-            gbf8 wbot = (gbf8)(blk_of(lb) + WX_BOT_OFF) + lane;
-#pragma unroll
-            for (int ks = 0; ks < X_KS; ++ks)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wb[ks][j] = wbot[(size_t)(ks * 4 + j) * 64];
-            const float* bp = (const float*)(blk_of(lb) + WX_CST_OFF) + CST_BBOT + 8 * g;
-            bb0 = *(const v4f*)bp; bb1 = *(const v4f*)(bp + 4);
-        };
-
         for (int l = a.l_begin; l < a.l_end; ++l) {
             const char* blk = blk_of(l);
             const float* lc = cbuf(l);
             const bool residual = (a.res_mask >> l) & 1u;
             const bool last_layer = l + 1 == a.l_end;
-            const bool defer = a.has_hw && l > a.l_begin;          // layer l-1's bottleneck runs behind this layer's GEMM
+            // the bottleneck of layer l-1 runs behind this layer's GEMM on the four older waves (the image is intact until the barrier);
+            // the segment's last layer has no GEMM behind it: a stage of its own, all eight waves
+            const bool defer = a.has_hw && l > a.l_begin && wave < NWAVE / 2;
             const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
             [[maybe_unused]] const int sb = 2 + (l - a.l_begin) * 8;
             XSTAMP(sb + 0);
             XFENCE();
-            if (!last_layer) cst_request(l + 1);
+            if (!last_layer) cst_request(l + 1, tid);
             {
                 float bias[8];
                 lds8(bias, lc + CST_BIAS + c0);
@@ -388,6 +418,12 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             XFENCE();
             XSTAMP(sb + 1);
 
+            // ---- the deferred bottleneck first (older waves), before the epilogue needs registers for the packed outputs
+            if (defer)
+                bottleneck_x<NWAVE / 2>(lds, (gbf8)(blk_of(l - 1) + WX_BOT_OFF) + lane, (const float*)(blk_of(l - 1) + WX_CST_OFF) + CST_BBOT,
+                                        a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            XFENCE();
+            XSTAMP(sb + 7);
             // ---- epilogue: ReLU, BatchNorm (folded), columns past the window forced to zero, split; the packed outputs wait in
             // registers for the barrier (the image is updated in place)
             bf8 oh[PT], ol[PT];
@@ -402,12 +438,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             auto store_tiles = [&]() {
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
-                    lds_write(lds, wa + t * (16 * P_ROW_BYTES), oh[t]);
-                    lds_write(lds + X_PLANE, wa + t * (16 * P_ROW_BYTES), ol[t]);
+                    lds_write(lds, wa + t * (16 * X_ROW_BYTES), oh[t]);
+                    lds_write(lds + X_LO, wa + t * (16 * X_ROW_BYTES), ol[t]);
                 }
             };
-            if (defer) bottleneck_request(l - 1);
-            else if (a.has_hw && last_layer && !residual) bottleneck_request(l);
             {
                 float sc[8], sh[8];
                 lds8(sc, lc + CST_SCALE + c0);
@@ -423,19 +457,11 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 }
             }
             // the first fragments of the next GEMM (this layer's residual 1x1, else the next layer's conv) ride under the barrier wait
-            {
-                const char* nb = residual ? blk : blk_of(last_layer ? l : l + 1);
-                load_first(pre_a, (gbf8)(nb + (residual ? WX_RES_OFF : WX_CONV_OFF)) + 4 * q * 64 + lane);
-            }
+            if (residual) load_first(pre_a, (gbf8)(blk + WX_RES_OFF) + 4 * q * 64 + lane);
+            else if (!last_layer) load_first(pre_a, (gbf8)(blk_of(l + 1) + WX_CONV_OFF) + 4 * q * 64 + lane);
             if (!last_layer) cst_put(l + 1);
             XFENCE();
             XSTAMP(sb + 2);
-            // ---- layer l-1's bottleneck, from the image this layer's GEMM has just read (intact until the barrier below)
-            if (defer) {
-                bottleneck_x(lds, wb, bb0, bb1, a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
-                if (a.has_hw && last_layer && !residual) bottleneck_request(l);
-            }
-            XSTAMP(sb + 7);
             __syncthreads();                                     // every read of the layer input is done
             XFENCE();
             XSTAMP(sb + 3);
@@ -446,7 +472,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                     lds8(br, lc + CST_BRES + c0);
 #pragma unroll
                     for (int t = 0; t < PT; ++t) {
-                        const bf8 xh = lds_read(lds, wa + t * (16 * P_ROW_BYTES)), xl = lds_read(lds + X_PLANE, wa + t * (16 * P_ROW_BYTES));
+                        const bf8 xh = lds_read(lds, wa + t * (16 * X_ROW_BYTES)), xl = lds_read(lds + X_LO, wa + t * (16 * X_ROW_BYTES));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             acc[0][t][j] = ((float)xh[j] + (float)xl[j]) + br[j];
@@ -461,8 +487,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 gemm_x<PT, 1>(acc, lds, xb1, xb1, xb1, wres, pre_a);
                 XFENCE();
                 XSTAMP(sb + 4);
-                load_first(pre_a, (gbf8)(blk_of(last_layer ? l : l + 1) + WX_CONV_OFF) + 4 * q * 64 + lane);
-                if (a.has_hw && last_layer) bottleneck_request(l);
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
                     float v[8];
@@ -470,6 +494,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                     for (int j = 0; j < 4; ++j) { v[j] = acc[0][t][j]; v[4 + j] = acc[1][t][j]; }
                     pack_tile(t, v);
                 }
+                if (!last_layer) load_first(pre_a, (gbf8)(blk_of(l + 1) + WX_CONV_OFF) + 4 * q * 64 + lane);
                 __syncthreads();                                 // every read of t is done
                 XFENCE();
             }
@@ -478,13 +503,20 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             XFENCE();
             XSTAMP(sb + 5);
             if (a.tap && a.tap_layer == l + 1) copy_tap(CPAD);
-            if (last_layer && a.has_hw)
-                bottleneck_x(lds, wb, bb0, bb1, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            if (a.has_hw && last_layer)
+                bottleneck_x<NWAVE>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
+                                    a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
             XSTAMP(sb + 6);
         }
         XSTAMP(62);
-        // ---- the segment's output -> y (both planes); every chunk of the thread is read before the image is handed to the next
-        // row's DMA
+        // ---- row end.  Requests for the next row first (see above), then the segment's output -> y: every chunk of the thread is read
+        // from the image (both planes, coalesced 1-KiB stores), a barrier hands the image to the next row's DMA, the DMA is issued
+        // and only then the stores.
+        if (next_row >= 0) {
+            first_request(tid);
+            if (resumed) { if (a.pool) seed_request(next_row, lane); }
+            else token_request(next_row, tid);
+        }
         {
             bf8* ydst = (bf8*)(a.y + read_idx * y_row);
             constexpr int NC = (2 * X_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;     // 13
@@ -494,7 +526,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             for (int k2 = 0; k2 < NC; ++k2) {
                 const int i = tid + k2 * SEG_THREADS;
                 const int pl = i >= n8 ? 1 : 0, ii = min(i - pl * n8, n8 - 1);
-                v[k2] = lds_read(lds + pl * X_PLANE, cell_addr(P_HALO + (ii >> 4), ii & 15));
+                v[k2] = lds_read(lds + pl * X_LO, cell_addr(P_HALO + (ii >> 4), ii & 15));
             }
             __syncthreads();                                     // every read of the image is done: the next row may land in it
             if (resumed && next_row >= 0) dma_read(next_row, lane);
@@ -504,7 +536,6 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 if (i < 2 * n8) ydst[i] = v[k2];
             }
         }
-        if (resumed && a.pool && next_row >= 0) seed_request(next_row, lane);
         XSTAMP(63);
     }
 }
@@ -519,6 +550,8 @@ void launch_segmentx(const SegmentXArgs& a0, int n_sites, int n_cus, hipStream_t
     wgs = (wgs + 7) / 8 * 8;
     const int need = (a.slice_rows < 1 ? 1 : a.slice_rows) * 8;   // no more workgroups than rows per slice x 8
     if (wgs > need) wgs = need;
+    // one row takes ~30 us (layers 1-2) / ~100 us (layers 3-7): the offsets spread the workgroups over about one row
+    if (a.stagger < 0) a.stagger = (a.l_end - a.l_begin) <= 2 ? 1 : 3;
     hipLaunchKernelGGL(x3::segmentx_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
 }
 
