@@ -70,15 +70,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& lo) {
         lo[j] = (__bf16)(v[j] - (float)hi[j]);
     }
 }
-// zero the 16 bytes of a lane whose column lies past the window
-__device__ __forceinline__ bf8 keep_if(bf8 o, bool keep) {
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    u4 w4 = __builtin_bit_cast(u4, o);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = keep ? w4[j] : 0u;
-    return __builtin_bit_cast(bf8, w4);
-}
-
 // LDS-DMA (see dan_kernels_bf16p.hip::glds16): 64 lanes x 16 bytes from per-lane global addresses to lds_base + 16 * lane
 __device__ __forceinline__ void glds16(const void* src, char* lds_base) {
     const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_base;
@@ -97,9 +88,12 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_base) {
 // (Tried: the previous layer's bottleneck folded into this walk -- its B operands ARE the centre tap's fragments.  The units
 // cannot be dealt evenly over four waves with one code path; per-tile tests of the wave's share cut the steps into blocks that
 // hipcc schedules one by one, per-wave copies of the whole walk tripled the spills: 18 k -> 23 k cycles per layer either way.)
+// skip_last (wave-uniform): the wave's last column tile lies past the window entirely (the second half's seventh tile when
+// L <= 208) -- its MFMAs are jumped over, 13 tiles per SIMD instead of 14.  (One branch per step; two copies of the whole walk,
+// chosen once per layer, cost 114 spilled registers where the copies' register assignments meet.)
 template <int PT, int TAPS>
 __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8 w,
-                                       const bf8 (&first)[2][4], bool k_short = false) {
+                                       const bf8 (&first)[2][4], bool k_short, bool skip_last) {
     constexpr int S = TAPS * X_KS, NA = 3, RING = 4, N = S * PT;
     bf8 a[NA][4], bh[RING], bl[RING];
 #pragma unroll
@@ -127,17 +121,21 @@ __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsig
             const int i = s * PT + t, in = i + RING - 1;
             if (in < N) { bh[in % RING] = lds_read(lds, xaddr(in)); bl[in % RING] = lds_read(lds + X_LO, xaddr(in)); }
             const bf8 xh = bh[i % RING], xl = bl[i % RING];
-            acc[0][t] = mfma16(a[s % NA][0], xh, acc[0][t]);
-            acc[1][t] = mfma16(a[s % NA][2], xh, acc[1][t]);
-            acc[0][t] = mfma16(a[s % NA][1], xh, acc[0][t]);
-            acc[1][t] = mfma16(a[s % NA][3], xh, acc[1][t]);
-            acc[0][t] = mfma16(a[s % NA][0], xl, acc[0][t]);
-            acc[1][t] = mfma16(a[s % NA][2], xl, acc[1][t]);
+            if (t + 1 < PT || !skip_last) {
+                acc[0][t] = mfma16(a[s % NA][0], xh, acc[0][t]);
+                acc[1][t] = mfma16(a[s % NA][2], xh, acc[1][t]);
+                acc[0][t] = mfma16(a[s % NA][1], xh, acc[0][t]);
+                acc[1][t] = mfma16(a[s % NA][3], xh, acc[1][t]);
+                acc[0][t] = mfma16(a[s % NA][0], xl, acc[0][t]);
+                acc[1][t] = mfma16(a[s % NA][2], xl, acc[1][t]);
+            }
         }
         if (s + NA < S) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[s % NA][j] = w[(size_t)((s + NA) * 16 + j) * 64];
         }
+        // (a fence per tile -- reads for the tile RING - 1 ahead, six MFMAs, fence -- gave the intended ISA for the 1x1 walk and a
+        // 3-tap walk sixty times slower: 464 spilled scalar registers, reloaded through memory inside the loop)
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -222,6 +220,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
     const int q = wave & 3, half = wave >> 2;
     const int L = a.L;
     const int pbase = half * (PT * 16);
+    const bool phantom = pbase + 16 * (PT - 1) >= L;             // (wave-uniform) the wave's last tile lies past the window entirely
     // behind the two planes: the per-channel constants (bias, scale, shift, bres: 512 floats) of the current layer and of the
     // next one, staged a layer ahead
     auto cbuf = [&](int l) { return (float*)(lds + X_IMG_BYTES + (l & 1) * 2048); };
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             }
             const unsigned xb0 = cell_addr(row0 - dil, g), xb1 = cell_addr(row0, g), xb2 = cell_addr(row0 + dil, g);
             gbf8 wconv = (gbf8)(blk + WX_CONV_OFF) + 4 * q * 64 + lane;
-            gemm_x<PT, 3>(acc, lds, xb0, xb1, xb2, wconv, pre_a, l == 0);
+            gemm_x<PT, 3>(acc, lds, xb0, xb1, xb2, wconv, pre_a, l == 0, phantom);
             XFENCE();
             XSTAMP(sb + 1);
 
@@ -427,19 +426,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // ---- epilogue: ReLU, BatchNorm (folded), columns past the window forced to zero, split; the packed outputs wait in
             // registers for the barrier (the image is updated in place)
             bf8 oh[PT], ol[PT];
-            auto pack_tile = [&](int t, const float (&v)[8]) {
-                split8(v, oh[t], ol[t]);
-                if (pbase + 16 * t + 16 > L) {                    // (uniform) the tile reaches past the window
-                    const bool keep = pbase + 16 * t + n < L;
-                    oh[t] = keep_if(oh[t], keep);
-                    ol[t] = keep_if(ol[t], keep);
-                }
-            };
+            auto pack_tile = [&](int t, const float (&v)[8]) { split8(v, oh[t], ol[t]); };
+            // (columns past the window are never stored: their rows stay zero from the start -- a lane predicate on the two stores of
+            // the tile that straddles L instead of eight v_cndmask per tile)
             auto store_tiles = [&]() {
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
-                    lds_write(lds, wa + t * (16 * X_ROW_BYTES), oh[t]);
-                    lds_write(lds + X_LO, wa + t * (16 * X_ROW_BYTES), ol[t]);
+                    if (pbase + 16 * t + n < L) {
+                        lds_write(lds, wa + t * (16 * X_ROW_BYTES), oh[t]);
+                        lds_write(lds + X_LO, wa + t * (16 * X_ROW_BYTES), ol[t]);
+                    }
                 }
             };
             {
@@ -484,7 +480,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 __syncthreads();
                 XFENCE();
                 gbf8 wres = (gbf8)(blk + WX_RES_OFF) + 4 * q * 64 + lane;
-                gemm_x<PT, 1>(acc, lds, xb1, xb1, xb1, wres, pre_a);
+                gemm_x<PT, 1>(acc, lds, xb1, xb1, xb1, wres, pre_a, false, phantom);
                 XFENCE();
                 XSTAMP(sb + 4);
 #pragma unroll
@@ -499,6 +495,13 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 XFENCE();
             }
             store_tiles();
+            if (last_layer && next_row >= 0) {
+                // requests for the NEXT row (see above): issued here, behind the layer's last use of the accumulators, they travel under
+                // the barrier, the segment's last bottleneck and the copy-out reads
+                first_request(tid);
+                if (resumed) { if (a.pool) seed_request(next_row, lane); }
+                else token_request(next_row, tid);
+            }
             __syncthreads();
             XFENCE();
             XSTAMP(sb + 5);
@@ -509,14 +512,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             XSTAMP(sb + 6);
         }
         XSTAMP(62);
-        // ---- row end.  Requests for the next row first (see above), then the segment's output -> y: every chunk of the thread is read
+        // ---- row end: the segment's output -> y: every chunk of the thread is read
         // from the image (both planes, coalesced 1-KiB stores), a barrier hands the image to the next row's DMA, the DMA is issued
         // and only then the stores.
-        if (next_row >= 0) {
-            first_request(tid);
-            if (resumed) { if (a.pool) seed_request(next_row, lane); }
-            else token_request(next_row, tid);
-        }
         {
             bf8* ydst = (bf8*)(a.y + read_idx * y_row);
             constexpr int NC = (2 * X_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;     // 13
