@@ -426,7 +426,13 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // ---- epilogue: ReLU, BatchNorm (folded), columns past the window forced to zero, split; the packed outputs wait in
             // registers for the barrier (the image is updated in place)
             bf8 oh[PT], ol[PT];
-            auto pack_tile = [&](int t, const float (&v)[8]) { split8(v, oh[t], ol[t]); };
+            // (the empty asm pins the packed values HERE, ahead of the barrier: they are stored under a lane predicate, and hipcc
+            // sinks the whole split into those predicated blocks behind the barrier -- where all eight waves then do their vector
+            // work at once instead of each in its own wait)
+            auto pack_tile = [&](int t, const float (&v)[8]) {
+                split8(v, oh[t], ol[t]);
+                asm volatile("" : "+v"(oh[t]), "+v"(ol[t]));
+            };
             // (columns past the window are never stored: their rows stay zero from the start -- a lane predicate on the two stores of
             // the tile that straddles L instead of eight v_cndmask per tile)
             auto store_tiles = [&]() {
