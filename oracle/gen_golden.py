@@ -292,6 +292,36 @@ def gen_model_fixtures(m):
         json.dump(log, f, indent=1)
 
 
+def gen_bf16_fixtures(m):
+    """The pin of the oracle's bf16 = "operands" mode, as committed fixtures (it travels: tests/test_oracle_golden.py checks it on any
+    box; tests/test_vs_live_reference.py fuzzes the same comparison where /root/reference exists).  The reference run "on bf16
+    matrix cores" = run_reference(bf16_operands=True): conv / residual 1x1 / bottleneck weights rounded to bf16, the inputs of
+    those modules rounded to bf16 by forward-pre-hooks, fp32 sums, everything else (compression, FC, heads) the reference's fp32."""
+    cases = {
+        "bf16_operands_small": (OracleSpec(reads=8, length=201, layers=7, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8)),
+                                concat(edge_sites(8), synth.make_sites(5, reads=8, seed=5)), 11),
+        "bf16_operands_l301": (OracleSpec(reads=6, length=301, layers=7, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8)),
+                               synth.make_sites(4, reads=6, length=301, seed=801), 701),
+    }
+    for name, (spec, batch, seed) in cases.items():
+        sd = random_state_dict(spec, seed=seed)
+        out = run_reference(m, spec, sd, batch, taps=True, bf16_operands=True)
+        mine = dan_forward_oracle(sd, spec, *batch.arrays(), taps=True, bf16="operands")
+        plain = dan_forward_oracle(sd, spec, *batch.arrays(), taps=True)
+        worst = moved = 0.0
+        for k, v in out.items():
+            sc = max(1.0, float(np.abs(v).max())) if v.size else 1.0
+            worst = max(worst, float(np.abs(mine[k] - v).max()) / sc)
+            moved = max(moved, float(np.abs(plain[k] - v).max()) / sc)
+        print("   oracle bf16='operands' vs reference with bf16-rounded GEMM operands [%s]: worst %.3g of max (fp32 oracle: %.3g away)"
+              % (name, worst, moved))
+        assert worst < 2e-5 and moved > 1e-4
+        keep = {k: v for k, v in out.items() if not k.startswith("conv")}
+        keep["conv2"] = out["conv2"][:4]
+        keep["conv7"] = out["conv7"][:4]
+        save_case(name, spec, sd, batch, keep)
+
+
 VCF_TABLE = [
     # (REF, ALT, window edits)   -- window edits: list of (col, token)
     ("A", "G", []),
@@ -486,9 +516,11 @@ def gen_cli_fixture():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     m, d, u = import_reference()
-    which = sys.argv[1:] or ["model", "dataset", "vcf", "cli"]
+    which = sys.argv[1:] or ["model", "bf16", "dataset", "vcf", "cli"]
     if "model" in which:
         gen_model_fixtures(m)
+    if "bf16" in which:
+        gen_bf16_fixtures(m)
     if "dataset" in which:
         gen_dataset_fixtures(d, u)
     if "vcf" in which:
