@@ -942,12 +942,16 @@ int64_t dan_read_buffer(dan_t* h, const char* name, float* dst, int64_t capacity
         if (!h->d_h) return fail(h, DAN_ERR_STATE, "the network has no highway bottleneck");
         const int64_t per_layer = (int64_t)h->last_chunk_sites * c.reads * c.length * HPAD;
         const int64_t stride = (int64_t)h->chunk * c.reads * c.length * HPAD;
+        if (per_layer == 0) return fail(h, DAN_ERR_STATE, "dan_read_buffer('h') before the first forward");
+        if (capacity < per_layer)
+            return fail(h, DAN_ERR_INVALID_ARG, "dan_read_buffer('h'): capacity %lld is less than one layer (%lld floats)", (long long)capacity,
+                        (long long)per_layer);
         n = std::min<int64_t>(per_layer * c.layers, capacity) / per_layer * per_layer;
         HIPCHK(h, hipSetDevice(c.device_id));
         HIPCHK(h, hipDeviceSynchronize());
+        std::vector<uint16_t> tmp(h->use_p ? (size_t)per_layer : 0);
         for (int64_t l = 0; l * per_layer < n; ++l) {
             if (h->use_p) {
-                std::vector<uint16_t> tmp((size_t)per_layer);
                 HIPCHK(h, hipMemcpy(tmp.data(), (const uint16_t*)h->d_h + l * stride, (size_t)per_layer * 2, hipMemcpyDeviceToHost));
                 for (int64_t i = 0; i < per_layer; ++i) dst[l * per_layer + i] = bf16_float(tmp[(size_t)i]);
             } else {

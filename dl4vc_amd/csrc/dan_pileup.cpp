@@ -83,6 +83,7 @@ struct Bgzf {
         uint32_t crc, isize;
         memcpy(&crc, raw.data() + body - 8, 4);
         memcpy(&isize, raw.data() + body - 4, 4);
+        if (isize > 65536) { err = "BGZF block claims more than 64 KiB of data"; return false; }   // (the format's limit; not a size to trust)
         data.resize(isize);
         uint8_t scratch[8];
         z_stream zs{};
@@ -273,11 +274,14 @@ struct Bam {
         if (r.read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) { err = path + " is not a BAM file"; return false; }
         int32_t l_text = 0, n_ref = 0;
         if (r.read(&l_text, 4) != 4) { err = "truncated BAM header"; return false; }
-        std::vector<char> text((size_t)std::max(0, l_text));
+        if (l_text < 0 || l_text > (1 << 30)) { err = "corrupt BAM header (text length)"; return false; }
+        std::vector<char> text((size_t)l_text);
         if (r.read(text.data(), text.size()) != text.size() || r.read(&n_ref, 4) != 4) { err = "truncated BAM header"; return false; }
+        if (n_ref < 0) { err = "corrupt BAM header (reference count)"; return false; }
         for (int i = 0; i < n_ref; ++i) {
             int32_t ln = 0, len = 0;
             if (r.read(&ln, 4) != 4) { err = "truncated BAM header"; return false; }
+            if (ln < 1 || ln > 65536) { err = "corrupt BAM header (reference name length)"; return false; }
             std::vector<char> nm((size_t)ln);
             if (r.read(nm.data(), nm.size()) != nm.size() || r.read(&len, 4) != 4) { err = "truncated BAM header"; return false; }
             refs.emplace_back(nm.data(), ln > 0 ? (size_t)ln - 1 : 0);
@@ -297,9 +301,11 @@ struct Bam {
     int next(std::shared_ptr<Rec>& out) {
         int32_t size = 0;
         const size_t g = r.read(&size, 4);
-        if (g < 4) return r.err.empty() ? 0 : -1;
+        if (g < 4) { if (!r.err.empty()) err = r.err; return r.err.empty() ? 0 : -1; }
+        // every length below comes from the file: checked against the record before anything is sized or indexed by it
+        if (size < 32 || size > (1 << 28)) { err = "corrupt BAM record (block_size)"; return -1; }
         std::vector<uint8_t> b((size_t)size);
-        if (r.read(b.data(), b.size()) != b.size()) { err = "truncated BAM record"; return -1; }
+        if (r.read(b.data(), b.size()) != b.size()) { err = r.err.empty() ? "truncated BAM record" : r.err; return -1; }
         auto rec = std::make_shared<Rec>();
         int32_t tid, pos, l_seq;
         uint8_t l_name;
@@ -307,6 +313,10 @@ struct Bam {
         memcpy(&tid, &b[0], 4); memcpy(&pos, &b[4], 4);
         l_name = b[8];
         memcpy(&n_cig, &b[12], 2); memcpy(&flag, &b[14], 2); memcpy(&l_seq, &b[16], 4);
+        if (l_seq < 0 || (uint64_t)32 + l_name + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > (uint64_t)size) {
+            err = "corrupt BAM record (name / CIGAR / sequence lengths exceed the record)";
+            return -1;
+        }
         rec->tid = tid; rec->pos = pos; rec->flag = flag;
         size_t o = 32;
         rec->name.assign((const char*)&b[o], l_name > 0 ? (size_t)l_name - 1 : 0);
@@ -648,6 +658,7 @@ int pe_encode(pe_encoder_t* e, const char* const* contigs, const int32_t* positi
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : 1, n));
     std::vector<std::string> errors((size_t)nt);
     auto work = [&](int ti) {
+      try {                                                  // (an exception leaving a std::thread terminates the process)
         const int64_t lo = n * ti / nt, hi = n * (ti + 1) / nt;
         Bam bam;
         Fasta fasta;
@@ -664,6 +675,11 @@ int pe_encode(pe_encoder_t* e, const char* const* contigs, const int32_t* positi
             status_out[i] = (int8_t)st;
         }
         fclose(bam.r.f);
+      } catch (const std::exception& ex) {
+        errors[ti] = std::string("pileup encoder: ") + ex.what();
+      } catch (...) {
+        errors[ti] = "pileup encoder: unknown exception";
+      }
     };
     std::vector<std::thread> pool;
     for (int ti = 1; ti < nt; ++ti) pool.emplace_back(work, ti);

@@ -17,7 +17,8 @@ import numpy as np
 from .synth import SiteBatch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdl4vc_loader.so")
+# (DL4VC_LOADER_LIB: another build of the same library -- the CPU AddressSanitizer pass of tools/asan_pileup.sh)
+LIB_PATH = os.environ.get("DL4VC_LOADER_LIB") or os.path.join(_HERE, "csrc", "libdl4vc_loader.so")
 SYMBOLS = ("dl_open", "dl_num_records", "dl_num_sites", "dl_window", "dl_next", "dl_close", "dl_last_error",
            "dl_select_rows", "dl_allele_masks", "pe_open", "pe_encode", "pe_close", "pe_last_error")
 _lib = None

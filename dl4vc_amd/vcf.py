@@ -230,17 +230,16 @@ def threshold_distance(vcfrecs: Sequence[str], vt_prob, options: FormatOptions =
     import numpy as np
     o = options or FormatOptions()
     th = _Thresholds(o)
-    vt = np.asarray(vt_prob, np.float64)
-    out = np.empty(len(vcfrecs), np.float64)
-    for i, rec in enumerate(vcfrecs):
-        f = rec.split("\t")
-        thr, hz = th.pick(f[3], f[4])
-        call = 1.0 - vt[i, 0]
-        d = [abs(call - thr), abs(vt[i, 2] - hz)]
-        if call >= thr:
-            d += [abs(call - o.multiallele_second_threshold), abs(call - o.multiallele_homozygous_second_threshold)]
-        out[i] = min(d)
-    return out
+    vt = np.asarray(vt_prob, np.float64).reshape(-1, 3)
+    if len(vcfrecs) == 0:
+        return np.empty(0, np.float64)
+    # one pass over the records for their allele class (REF / ALT columns only), the distances as array arithmetic: this runs on
+    # the scoring path (main.py, every delivered batch), not in a post-processing tool
+    picks = np.array([th.pick(*rec.split("\t", 5)[3:5]) for rec in vcfrecs], np.float64).reshape(-1, 2)
+    call = 1.0 - vt[:, 0]
+    d = np.minimum(np.abs(call - picks[:, 0]), np.abs(vt[:, 2] - picks[:, 1]))
+    multi = np.minimum(np.abs(call - o.multiallele_second_threshold), np.abs(call - o.multiallele_homozygous_second_threshold))
+    return np.where(call >= picks[:, 0], np.minimum(d, multi), d)
 
 
 def format_vcf(input_file: str, output_file: str, options: FormatOptions = None) -> None:

@@ -179,11 +179,20 @@ def train_main(args, argv) -> int:
             # rank r scores a contiguous run of the test batches with the parameters every rank holds (rank 0's BatchNorm
             # running statistics, broadcast -- DataParallel keeps replica 0's), the loss sums are reduced, the record text is
             # concatenated in rank order = batch order.  No rank idles in a barrier while rank 0 walks a genome-scale file.
+            # Only the BatchNorm running statistics can differ between ranks (parameters are identical behind the averaged step;
+            # statistics are per replica): those few vectors are broadcast, not the pickled 311-MB state dict.
             state = trainer.state_dict()
             if dist is not None:
-                box = [state if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                state = box[0]
+                import torch
+                on_gpu = dist.get_backend() == "nccl"
+                for key in sorted(k for k in state if k.startswith("bn1D_layers.") and
+                                  k.rsplit(".", 1)[1] in ("running_mean", "running_var", "num_batches_tracked")):
+                    v = np.ascontiguousarray(state[key])
+                    t = torch.from_numpy(v.copy())
+                    if on_gpu:
+                        t = t.cuda()
+                    dist.broadcast(t, src=0)
+                    state[key] = t.cpu().numpy().astype(v.dtype).reshape(v.shape)
             net = DanNet(cfg, device_id=0, max_batch=args.test_batch_size).load_state_dict(state)
             out_path = None
             if args.save_vcf_records:
@@ -301,15 +310,17 @@ def main(argv=None) -> int:
     else:
         target = out_final + ".records"
     t_loop = time.time()
-    stats = {}
+    stats = None if os.environ.get("DL4VC_NO_THRESHOLD_STATS") else {}      # (the near-threshold count is a log line: opt out for raw rate)
     n = run_shard(net, args.test_file, target, shard_i, shard_n, sites_per_launch=args.sites_per_launch,
                   reads_seed=args.reads_seed, use_var_type_threshold=args.use_var_type_threshold,
                   holdout_chromosomes=holdout, site_limit=site_limit, log=lambda m: print(m, end="\r"), stats=stats)
     t_loop = time.time() - t_loop
     net.close()
-    print("\n%d of %d sites lie within 1e-4 of a genotype threshold of the published pipeline (format_vcf flags of "
-          "call_variants.sh:154-160): only there could a call differ from another correct fp32 evaluation of the same scores"
-          % (stats.get("near_threshold", 0), stats.get("sites", 0)))
+    if stats is not None:
+        print("\n%d of %d sites lie within 1e-4 of a genotype threshold of the published pipeline (format_vcf flags of "
+              "call_variants.sh:154-160; main.py has no threshold flags of its own -- tools/format_vcf.py takes them later): only "
+              "there could a call differ from another correct fp32 evaluation of the same scores"
+              % (stats.get("near_threshold", 0), stats.get("sites", 0)))
     print("\nscoring loop (HDF5 read + assembly + forward + VCF text): %d sites in %.2f s = %.0f sites/s" % (n, t_loop, n / max(t_loop, 1e-9)))
     if shard_n == 1:
         if args.sample_vcf:

@@ -202,3 +202,72 @@ def test_native_is_much_faster_than_the_python_path(tmp_path):
 def test_open_errors_are_reported():
     with pytest.raises(RuntimeError, match="cannot open|not a BAM"):
         loader.NativePileupEncoder("/nonexistent.bam", "/nonexistent.fa", 100, 200, 10, 50)
+
+
+def _corrupt_bam(tmp_path, tag, raw_records, good_before=3):
+    """A BAM whose header is well-formed, holding ``good_before`` valid reads and then the given RAW record bytes (length prefix
+    included) -- what a damaged or hostile file looks like behind intact BGZF framing."""
+    import struct
+    from dl4vc_amd.bamio import pack_record
+    ref = "ACGT" * 200
+    fa = str(tmp_path / ("%s.fa" % tag))
+    with open(fa, "w") as f:
+        f.write(">ref\n%s\n" % ref)
+    bam = str(tmp_path / ("%s.bam" % tag))
+    with BamWriter(bam, [("ref", len(ref))]) as w:
+        for i in range(good_before):
+            w.write(0, 100 + i, "r%d" % i, 0, 60, [(0, 50)], ref[100 + i:150 + i], [30] * 50)
+        for raw in raw_records:
+            w.w.write(raw)
+    return bam, fa, struct, pack_record
+
+
+@pytest.mark.parametrize("damage", ["l_seq_beyond_record", "negative_l_seq", "negative_block_size", "tiny_block_size",
+                                    "cigar_count_beyond_record", "truncated_record"])
+def test_corrupt_bam_records_are_an_error_not_a_crash(tmp_path, damage):
+    """every length field of a BAM record comes from the file.  A record whose l_seq / n_cigar_op / l_read_name run
+    past its block_size, a negative or tiny block_size, a record cut off by the end of the file: pe_encode reports an error
+    (RuntimeError through the wrapper) -- on one thread and inside worker threads (an exception escaping a std::thread would
+    terminate the interpreter).  Run once under the CPU AddressSanitizer build as well (tools/asan_pileup.sh)."""
+    import struct
+    from dl4vc_amd.bamio import pack_record
+    good = pack_record(0, 120, "bad", 0, 60, [(0, 50)], "ACGT" * 12 + "AC", [30] * 50)
+    body = bytearray(good[4:])
+    if damage == "l_seq_beyond_record":
+        body[16:20] = struct.pack("<i", 100000)
+        raw = struct.pack("<i", len(body)) + bytes(body)
+    elif damage == "negative_l_seq":
+        body[16:20] = struct.pack("<i", -5)
+        raw = struct.pack("<i", len(body)) + bytes(body)
+    elif damage == "negative_block_size":
+        raw = struct.pack("<i", -1) + bytes(body)
+    elif damage == "tiny_block_size":
+        raw = struct.pack("<i", 8) + bytes(body[:8])
+    elif damage == "cigar_count_beyond_record":
+        body[12:14] = struct.pack("<H", 60000)
+        raw = struct.pack("<i", len(body)) + bytes(body)
+    else:
+        raw = struct.pack("<i", len(body)) + bytes(body[:40])            # the file ends inside the record
+    bam, fa, _, _ = _corrupt_bam(tmp_path, damage, [raw])
+    for threads in (1, 3):
+        with loader.NativePileupEncoder(bam, fa, 16, 50, 10, 50) as enc:
+            with pytest.raises(RuntimeError, match="corrupt BAM record|truncated BAM record|BGZF"):
+                enc.encode(["ref"] * 6, [110, 115, 120, 125, 130, 135], threads)
+
+
+def test_corrupt_bam_header_is_reported(tmp_path):
+    import struct
+    from dl4vc_amd.bamio import BgzfWriter
+    for tag, payload in (("neg_text", b"BAM\x01" + struct.pack("<i", -7)),
+                         ("neg_name", b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", -3)),
+                         ("neg_nref", b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", -2))):
+        path = str(tmp_path / (tag + ".bam"))
+        with open(path, "wb") as f:
+            w = BgzfWriter(f, 6)
+            w.write(payload)
+            w.close()
+        fa = str(tmp_path / (tag + ".fa"))
+        with open(fa, "w") as f:
+            f.write(">ref\nACGT\n")
+        with pytest.raises(RuntimeError, match="corrupt BAM header|truncated BAM header"):
+            loader.NativePileupEncoder(path, fa, 16, 50, 10, 50)
