@@ -109,15 +109,16 @@ def _rank_exchange(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradient_exchange_buckets_direct_and_allreduce_world3_gloo():
+@pytest.mark.parametrize("world", [3, 8])
+def test_gradient_exchange_buckets_direct_and_allreduce_gloo(world):
     """The bucketed exchange: direct reduce-scatter (all-to-all of 1/world chunks + rank-ordered shard
     sum) + all-gather, with the remainder that world does not divide all-reduced, equals the plain all-reduce mean, and
-    every rank ends with the same bits."""
+    every rank ends with the same bits.  World 3 and world 8 (BASELINE config 4's node: bucket 0 = 11 floats = 8 exchanged
+    directly + 3 left over, bucket 1 = 6 floats < world: all of it through the remainder path)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31600 + (os.getpid() % 2000)
-    world = 3
+    port = 31600 + (os.getpid() % 2000) + world
     ps = [ctx.Process(target=_rank_exchange, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
@@ -125,7 +126,7 @@ def test_gradient_exchange_buckets_direct_and_allreduce_world3_gloo():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    want = ((np.arange(17) + 1) * (1 + 4 + 9) / 3.0).astype(np.float32)
+    want = ((np.arange(17) + 1) * sum((r + 1) ** 2 for r in range(world)) / float(world)).astype(np.float32)
     for r in range(world):
         for direct in (True, False):
             assert np.allclose(got[r][direct], want, rtol=1e-6), (r, direct)
@@ -332,18 +333,21 @@ def _rank_short_tail(rank, world, port, path, q):
         dist.destroy_process_group()
 
 
-def test_short_last_batch_leaves_a_rank_without_sites_world2_gloo(tmp_path):
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_short_last_batch_leaves_ranks_without_sites_gloo(tmp_path, ranks):
     """9 sites in batches of 4 over 2 ranks: the last batch holds ONE site, so rank 1 has nothing in it (DataParallel's
     torch.chunk split, main.py:117: it then runs one replica).  Both ranks finish both epochs (no collective left waiting),
     take the same number of optimiser steps, end with bit-identical parameters, and those equal the single-process run --
-    the averaged gradient is the full-batch gradient for the 2+2, 2+2 and 1+0 splits alike."""
+    the averaged gradient is the full-batch gradient for the 2+2, 2+2 and 1+0 splits alike.  At 8 ranks (the node of
+    BASELINE config 4) a batch of 4 leaves ranks 4-7 out of EVERY step and the one-site batch ranks 1-7: they sit the steps
+    out, join every exchange and stay bit-identical."""
     import torch.multiprocessing as mp
     from dl4vc_amd import hdf5io
     path = str(tmp_path / "train.hdf")
     hdf5io.write_candidates(path, _records(9, 8, 77))
     ctx = mp.get_context("spawn")
     res = {}
-    for world in (1, 2):
+    for world in (1, ranks):
         q = ctx.Queue()
         port = 33700 + (os.getpid() % 2000) + world
         ps = [ctx.Process(target=_rank_short_tail, args=(r, world, port, path, q)) for r in range(world)]
@@ -356,11 +360,11 @@ def test_short_last_batch_leaves_a_rank_without_sites_world2_gloo(tmp_path):
         res[world] = {r: (p_, s, f) for r, p_, s, f in got}
     p1, s1, f1 = res[1][0]
     assert s1 == 6                                                   # 3 batches x 2 epochs
-    for r in (0, 1):
-        p2, s2, f2 = res[2][r]
+    for r in range(ranks):
+        p2, s2, f2 = res[ranks][r]
         assert s2 == 6 and f2 == f1 == sorted(list(range(9)) * 2)    # every site's flags reached every rank's sampler, once per epoch
         assert np.allclose(p2, p1, rtol=1e-12, atol=1e-12), (r, p2, p1)
-    assert res[2][0][0] == res[2][1][0]                              # replicas identical bit for bit
+        assert res[ranks][r][0] == res[ranks][0][0]                  # replicas identical bit for bit
 
 
 def test_reference_parameter_order_and_optimizer_state_shape():
