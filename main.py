@@ -295,7 +295,28 @@ def main(argv=None) -> int:
                 except OSError:
                     pass
             raise SystemExit("shard process failed: %s" % rcs)
+        t_shards = time.time() - t0
+        # what each shard did (its own scoring-loop clock, written beside its part file) and what the host-side concat costs: the
+        # first run on a real multi-GPU node explains itself
+        import json
+        total = 0
+        for g in range(args.gpus):
+            side = part_path(out_final, g) + ".stats.json"
+            try:
+                with open(side) as f:
+                    st = json.load(f)
+                os.remove(side)
+                total += st["sites"]
+                print("\tshard %d/%d on device %s: %d sites, scoring loop %.2f s = %.0f sites/s (process %.2f s incl. start-up and "
+                      "checkpoint load)" % (g, args.gpus, devices[g], st["sites"], st["loop_s"], st["sites"] / max(st["loop_s"], 1e-9),
+                                            st["process_s"]))
+            except (OSError, ValueError, KeyError):
+                print("\tshard %d/%d: no statistics file" % (g, args.gpus))
+        t1 = time.time()
         concat_parts(out_final, args.gpus, header_from=args.sample_vcf)
+        t_cat = time.time() - t1
+        print("\t%d shards: %d sites in %.2f s = %.0f sites/s whole job; host-side concat %.3f s" %
+              (args.gpus, total, t_shards + t_cat, total / max(t_shards + t_cat, 1e-9), t_cat))
         print("\tTime elapsed for inference/testing {:.4f}".format(time.time() - t0))
         return 0
 
@@ -330,6 +351,10 @@ def main(argv=None) -> int:
         with open(out_final, "a") as out, open(target) as src:
             out.write(src.read())
         os.remove(target)
+    if shard_n > 1:
+        import json
+        with open(target + ".stats.json", "w") as f:
+            json.dump({"sites": int(n), "loop_s": t_loop, "process_s": time.time() - s_eval, "shard": shard_i, "of": shard_n}, f)
     print("\nscored %d sites -> %s" % (n, out_final if shard_n == 1 else target))
     print("\tTime elapsed for inference/testing {:.4f}".format(time.time() - s_eval))
     return 0

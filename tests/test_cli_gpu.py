@@ -56,6 +56,12 @@ def test_main_py_inference(tmp_path, gpus):
     import re
     counts = [(int(a), int(b)) for a, b in re.findall(r"(\d+) of (\d+) sites lie within 1e-4 of a genotype threshold", r.stdout)]
     assert len(counts) == gpus and sum(b for _, b in counts) == 24, r.stdout[-1500:]
+    if gpus == 2:
+        # the launcher reports every shard's own scoring-loop rate and the cost of the host-side concat (and leaves no side files)
+        shard_lines = re.findall(r"shard (\d)/2 on device \S+: (\d+) sites, scoring loop", r.stdout)
+        assert sorted(shard_lines) == [("0", "12"), ("1", "12")], r.stdout[-1500:]
+        assert re.search(r"2 shards: 24 sites in .* whole job; host-side concat", r.stdout), r.stdout[-1500:]
+        assert not [f for f in os.listdir(str(tmp_path)) if f.endswith(".stats.json") or ".part" in f]
     lines = open(str(tmp_path / "epoch1_model_test.vcf")).read().splitlines()
     assert lines[0].startswith("##fileformat") and lines[1].startswith("#CHROM")
     body = lines[2:]
