@@ -16,7 +16,7 @@ from .config import DanConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdl4vc_dan.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/dl4vc_dan.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ("dan_abi_version", "dan_create", "dan_set_tensor", "dan_finalize", "dan_destroy", "dan_last_error",
@@ -31,7 +31,8 @@ class DanCConfig(C.Structure):
                 ("pool_layers_mask", C.c_uint32), ("residual_start", C.c_int32), ("use_bn", C.c_int32),
                 ("use_q", C.c_int32), ("use_strand", C.c_int32), ("use_mask", C.c_int32), ("bottleneck", C.c_int32),
                 ("fc_sizes", C.c_int32 * 2), ("precision", C.c_int32), ("device_id", C.c_int32),
-                ("max_batch", C.c_int32), ("chunk_sites", C.c_int32), ("conv_algo", C.c_int32), ("skip_empty_rows", C.c_int32)]
+                ("max_batch", C.c_int32), ("chunk_sites", C.c_int32), ("conv_algo", C.c_int32), ("skip_empty_rows", C.c_int32),
+                ("bf16_form", C.c_int32)]
 
 
 _lib = None
@@ -84,7 +85,8 @@ def c_config(cfg: DanConfig, device_id: int = 0, max_batch: int = 0, chunk_sites
                       residual_start=cfg.residual_start, use_bn=int(cfg.use_bn), use_q=int(cfg.use_q),
                       use_strand=int(cfg.use_strand), use_mask=int(cfg.use_mask), bottleneck=cfg.bottleneck,
                       fc_sizes=(C.c_int32 * 2)(*cfg.fc_sizes), precision=cfg.precision, device_id=device_id,
-                      max_batch=max_batch, chunk_sites=chunk_sites, conv_algo=cfg.conv_algo, skip_empty_rows=int(cfg.skip_empty_rows))
+                      max_batch=max_batch, chunk_sites=chunk_sites, conv_algo=cfg.conv_algo, skip_empty_rows=int(cfg.skip_empty_rows),
+                      bf16_form=int(cfg.bf16_form))
 
 
 def _u8(a, shape, name):

@@ -48,6 +48,7 @@ class DanConfig:
     precision: int = PRECISION_F32
     conv_algo: int = 0                       # fp32 path: 0 auto, 1 direct 3-tap GEMM, 2 Winograd F(2,3) (include/dl4vc_dan.h)
     skip_empty_rows: bool = False            # all-padding pileup rows computed once per site (bit-identical outputs)
+    bf16_form: int = 0                       # precision 2: 0 = eight-wave kernel form (default), 1 = sixteen-wave form (include/dl4vc_dan.h)
 
     def __post_init__(self):
         object.__setattr__(self, "pool_layers", tuple(int(p) for p in self.pool_layers))
@@ -148,6 +149,8 @@ class DanConfig:
             raise UnsupportedModelOption("bottleneck >= 0 and exactly two FC layers required")
         if self.conv_algo not in (0, 1, 2):
             raise UnsupportedModelOption("conv_algo must be 0 (auto), 1 (direct) or 2 (winograd)")
+        if self.bf16_form not in (0, 1) or (self.bf16_form and self.precision != PRECISION_BF16):
+            raise UnsupportedModelOption("bf16_form is 0 or 1 and selects a form of the precision-2 (bf16) kernel")
         if self.embed_dim != 20:
             raise UnsupportedModelOption("embed_dim is fixed at 20 in the reference's scripts")
 

@@ -51,9 +51,8 @@ struct dan_handle {
     // device memory
     std::vector<void*> allocs;
     float* d_wl = nullptr;                   // [layers][LAYER_STRIDE] weight blocks (fp32 path)
-    char* d_wl16 = nullptr;                  // [layers][W16_LAYER_BYTES] bf16 hi/lo weight blocks (precision 1, 2)
     char* d_wlp = nullptr;                   // [layers][WP_LAYER_BYTES] 32x32x16 fragments of the ping-pong bf16 kernel (precision 2)
-    char* d_wlr = nullptr;                   // the same blocks as 16x16x32 fragments (sixteen-wave form, DAN_BF16_FORM=r)
+    char* d_wlr = nullptr;                   // the same blocks as 16x16x32 fragments (sixteen-wave form, dan_config.bf16_form = 1)
     float* d_wc16 = nullptr;                 // compression weights in the channel order of a 16-byte bf16 load of h
     float *d_wpool = nullptr, *d_cols = nullptr, *d_cp = nullptr, *d_zero = nullptr;   // conv(read-mean): weights [segment][128][384], scratch, result
     bool use_p = false;                      // precision 2 on dan_kernels_bf16p.hip: y and h cross HBM as bf16
@@ -244,23 +243,6 @@ void pack_fragx(uint16_t* dst, int taps, int ksteps, int n_ct, F W) {
             }
 }
 
-// MFMA 16x16x32 bf16 A-fragment order, hi plane then lo plane (lo = bf16(w - hi)):
-//   plane[((tap*kg + g)*tiles + n)*64 + lane][j] = W[o = 16n + (lane&15)][c = 32g + 8(lane>>4) + j][tap]
-template <typename F>
-void pack_frag16(uint16_t* dst, size_t plane_frags, int taps, int kg, int tiles, F W) {
-    size_t i = 0;
-    for (int t = 0; t < taps; ++t)
-        for (int g = 0; g < kg; ++g)
-            for (int n = 0; n < tiles; ++n)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j, ++i) {
-                        const float w = W(16 * n + (lane & 15), 32 * g + 8 * (lane >> 4) + j, t);
-                        const uint16_t hi = bf16_bits(w);
-                        dst[i] = hi;
-                        dst[plane_frags * 8 + i] = bf16_bits(w - bf16_float(hi));
-                    }
-}
-
 int prof_begin(dan_handle* h, const char* k, hipStream_t s, EventPair* ev) {
     if (!h->profiling) return 0;
     if (!h->event_pool.empty()) { *ev = h->event_pool.back(); h->event_pool.pop_back(); }
@@ -306,7 +288,7 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     if (c.reads < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "reads must be >= 1");
     if (c.precision < 0 || c.precision > 2)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "precision %d unknown (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)", c.precision);
-    const int max_len = c.precision == 2 ? MT_MAX16 * 16 : MPOS;
+    const int max_len = c.precision == 2 ? P_LMAX : MPOS;
     if (c.length < 8 || c.length > max_len)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the LDS-resident path at precision %d (8..%d)", c.length, c.precision, max_len);
     if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD)
@@ -325,6 +307,8 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     const bool wino_ok = c.precision == 0 && (c.layers < 3 || c.dil_mid == 2) && (c.layers < 2 || c.dil_final == 2);
     if (c.conv_algo < 0 || c.conv_algo > 2) return fail(nullptr, DAN_ERR_INVALID_ARG, "conv_algo %d unknown (0 = auto, 1 = direct, 2 = winograd)", c.conv_algo);
     if (c.skip_empty_rows < 0 || c.skip_empty_rows > 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "skip_empty_rows must be 0 or 1");
+    if (c.bf16_form < 0 || c.bf16_form > 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "bf16_form %d unknown (0 = eight waves, 1 = sixteen waves)", c.bf16_form);
+    if (c.bf16_form != 0 && c.precision != 2) return fail(nullptr, DAN_ERR_INVALID_ARG, "bf16_form selects a form of the precision-2 kernel");
     if (c.conv_algo == 2 && !wino_ok)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "conv_algo 2 (winograd) needs precision 0 and dilation 2 on every conv layer after the first");
     int ndev = 0;
@@ -338,10 +322,17 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         h->chunk = c.chunk_sites;
     } else {
         // default: the largest power-of-two chunk (<= the FC macro-batch) whose segment-boundary activations y and bottleneck
-        // outputs h stay under 48 GB -- 288 GB of HBM per GPU: fewer, larger launches (2048 sites at 64 x 201: +1.7 % over 128)
+        // outputs h stay under 48 GB -- 288 GB of HBM per GPU: fewer, larger launches (2048 sites at 64 x 201: +1.7 % over 128) --
+        // and under a third of what the device has FREE now (a shared or smaller device sizes down instead of failing in hipMalloc;
+        // the feature matrix, FC workspaces and weights take their share of the rest)
         const double per_site = (double)c.reads * c.length * (CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * sizeof(float);
+        double budget = 48e9;
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(c.device_id) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+            budget = std::min(budget, (double)free_b / 3.0);
         int chunk = 128;
-        while (chunk * 2 <= h->max_batch && (double)(chunk * 2) * per_site <= 48e9) chunk *= 2;
+        while (chunk * 2 <= h->max_batch && (double)(chunk * 2) * per_site <= budget) chunk *= 2;
+        while (chunk > 1 && (double)chunk * per_site > budget) chunk /= 2;
         h->chunk = chunk;
     }
     // the read-axis reductions put the chunk's site index in gridDim.y (limit 65 535): no chunk exceeds 32 768 sites,
@@ -389,20 +380,9 @@ int dan_finalize(dan_t* h) {
 
     // ---- conv stack: one fixed-stride weight block per layer (dan_kernels.h)
     std::vector<float> wl((size_t)c.layers * LAYER_STRIDE, 0.f);
-    std::vector<char> wl16(c.precision ? (size_t)c.layers * W16_LAYER_BYTES : 0, 0);    // (the eight-wave family: fallback forms)
-    // precision 2 runs on the ping-pong kernel (bf16 y / h in HBM) unless the structure needs the older forms or
-    // DAN_BF16_FORM = 4 | 8 asks for them (A/B runs, the form-vs-form tests)
-    {
-        const char* form_env = getenv("DAN_BF16_FORM");
-        bool ok = c.precision == 2 && !(form_env && (form_env[0] == '4' || form_env[0] == '8'));
-        unsigned rm = 0;
-        for (int l1 = 1; l1 <= c.layers; ++l1) if (is_residual(c, l1)) rm |= 1u << (l1 - 1);
-        for (int sg = 0; ok && sg < h->n_segments; ++sg) ok = segmentp_supports(L, h->seg_begin[sg], rm, sg > 0);
-        h->use_p = ok;
-        // precision 1 runs on the split kernel of dan_kernels_bf16x.hip (every structure; DAN_BF16_FORM = 8 keeps round 1's kernel
-        // for A/B runs)
-        h->use_x = c.precision == 1 && !(form_env && form_env[0] == '8');
-    }
+    // precision 2: the ping-pong kernel (bf16 y / h in HBM); precision 1: the split kernel (y as two bf16 planes)
+    h->use_p = c.precision == 2;
+    h->use_x = c.precision == 1;
     const bool conv_pool = h->use_p || h->use_x;                 // the read-mean enters the layer behind it as conv(pool)
     std::vector<char> wlp(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
     std::vector<char> wlr(h->use_p ? (size_t)c.layers * WP_LAYER_BYTES : 0, 0);
@@ -448,11 +428,6 @@ int dan_finalize(dan_t* h) {
             std::vector<float> pw = pack_frag(4, KGC, KGC, Wu);
             std::copy(pw.begin(), pw.end(), blk + WW_OFF);
         }
-        char* blk16 = c.precision ? wl16.data() + (size_t)l * W16_LAYER_BYTES : nullptr;
-        if (blk16) {
-            auto Wf16 = [&](int o, int cc, int t) -> float { return Wf(o, cc, t); };   // channels beyond kg*16 read as 0
-            pack_frag16((uint16_t*)(blk16 + W16_CONV_OFF), W16_CONV_FRAGS, 3, l == 0 ? KG16_0 : KG16_C, KGC, Wf16);
-        }
         char* blkp = h->use_p ? wlp.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
         if (blkp) pack_fragp((uint16_t*)(blkp + WP_CONV_OFF), 3, l == 0 ? P_KS0 : P_KSC, 4, Wf);
         char* blkr = h->use_p ? wlr.data() + (size_t)l * WP_LAYER_BYTES : nullptr;
@@ -489,7 +464,6 @@ int dan_finalize(dan_t* h) {
             auto Wr = [&](int o, int cc, int) -> float { return (o < cout && cc < cout) ? wr->data[(size_t)o * cout + cc] : 0.f; };
             std::vector<float> pr = pack_frag(1, KGC, KGC, Wr);
             std::copy(pr.begin(), pr.end(), blk + WRES_OFF);
-            if (blk16) pack_frag16((uint16_t*)(blk16 + W16_RES_OFF), W16_RES_FRAGS, 1, KG16_C, KGC, Wr);
             if (blkp) pack_fragp((uint16_t*)(blkp + WP_RES_OFF), 1, P_KSC, 4, Wr);
             if (blkr) pack_fragr((uint16_t*)(blkr + WP_RES_OFF), 1, 4, 8, Wr);
             if (blkx) pack_fragx((uint16_t*)(blkx + WX_RES_OFF), 1, X_KS, 8, Wr);
@@ -503,7 +477,6 @@ int dan_finalize(dan_t* h) {
             auto Wb = [&](int o, int cc, int) -> float { return (o < H && cc < cout) ? wb->data[(size_t)o * cout + cc] : 0.f; };
             std::vector<float> pb = pack_frag(1, KGC, 2, Wb);
             std::copy(pb.begin(), pb.end(), blk + WBOT_OFF);
-            if (blk16) pack_frag16((uint16_t*)(blk16 + W16_BOT_OFF), W16_BOT_FRAGS, 1, KG16_C, 2, Wb);
             if (blkp) pack_fragp((uint16_t*)(blkp + WP_BOT_OFF), 1, P_KSC, 1, Wb);
             if (blkr) pack_fragr((uint16_t*)(blkr + WP_BOT_OFF), 1, 4, 2, Wb);
             if (blkx) pack_fragx((uint16_t*)(blkx + WX_BOT_OFF), 1, X_KS, 2, Wb);
@@ -560,12 +533,6 @@ int dan_finalize(dan_t* h) {
         if ((rc = dev_upload(h, &h->d_wpool, wpool_all))) return rc;
         std::vector<float> zeros(CPAD, 0.f);
         if ((rc = dev_upload(h, &h->d_zero, zeros))) return rc;
-    }
-    if (c.precision && !h->use_x) {                          // constants are shared: copy each layer's fp32 block tail
-        for (int l = 0; l < c.layers; ++l)
-            memcpy(wl16.data() + (size_t)l * W16_LAYER_BYTES + W16_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
-                   CST_FLOATS * sizeof(float));
-        if ((rc = dev_upload(h, &h->d_wl16, wl16))) return rc;
     }
     if ((rc = dev_upload(h, &h->d_wl, wl))) return rc;
     if (H > 0) {
@@ -702,25 +669,17 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
                     b.y = (uint16_t*)h->d_y; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = h->d_h; b.h_layer_stride = a.h_layer_stride;
                     b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
-                    { const char* e = getenv("DAN_X_STAGGER"); b.stagger = e ? atoi(e) : -1; }   // (A/B switch while the kernel is tuned)
+                    b.stagger = -1;                              // (the launcher's own start offsets)
                     launch_segmentx(b, ns, h->n_cus, s);
                 } else if (h->use_p) {
                     SegmentPArgs b{};
-                    b.wl = h->d_wlp; b.wlr = h->d_wlr; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
+                    b.wl = h->d_wlp; b.wlr = h->d_wlr; b.form = c.bf16_form; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
                     b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
                     b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
                     b.y = (uint16_t*)h->d_y; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = (uint16_t*)h->d_h; b.h_layer_stride = a.h_layer_stride;
                     b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
                     launch_segmentp(b, ns, h->n_cus, s);
-                } else {
-                    Segment16Args b{};
-                    b.wl = h->d_wl16; b.l_begin = a.l_begin; b.l_end = a.l_end; b.n_layers = a.n_layers;
-                    b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
-                    b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
-                    b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe; b.y = a.y; b.pool = a.pool;
-                    b.h = a.h; b.h_layer_stride = a.h_layer_stride; b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
-                    launch_segment16(b, ns, c.precision, h->n_cus, s);
                 }
                 rc = prof_end(h, "conv_segment", s, &ev); if (rc) return rc;
                 if (sg + 1 < h->n_segments) {

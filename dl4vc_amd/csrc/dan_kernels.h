@@ -15,8 +15,6 @@ constexpr int SEG_THREADS = NWAVE * 64;
 // matrix pipe ~7.4 cycles: tools/ubench/mfma_feed.hip).
 constexpr int NT = 2;
 constexpr int MTW = 7;                  // position tiles per wave (the upper half uses MT - MTW = 6 of them)
-// bf16 kernels: every wave owns one 16-channel tile x all position tiles
-constexpr int NT16 = 1;
 constexpr int MT = 13;                  // 16-position tiles per read         (L <= 208)
 constexpr int MPOS = MT * 16;           // 208
 constexpr int HALO = 4;                 // zero rows either side of the window (dilation <= 4)
@@ -76,43 +74,6 @@ struct SegmentArgs {
 // max_wgs: workgroups to launch (one per CU: they are persistent and walk the rows with the grid's stride); 0 = one per row
 void launch_segment(const SegmentArgs& a, int n_sites, int max_wgs, hipStream_t s);
 
-// ---- bf16-MFMA family (dan_kernels_bf16.hip): precision 1 = bf16x3 (hi+lo split, L <= 208), 2 = bf16 (L <= 304)
-constexpr int S16 = 144;                 // bf16 elements per LDS position row (256 B + 32 B: conflict-free b128 reads)
-constexpr int KG16_0 = 2;                // 32-channel k-groups of layer 1 (48 encoded channels padded to 64)
-constexpr int KG16_C = CPAD / 32;        // 4
-constexpr int MT_MAX16 = 19;             // position tiles of the plain-bf16 instantiation (L <= 304)
-// per-layer weight block (bytes): every matrix as MFMA A fragments [step][tile][lane 64][8 bf16], hi plane then lo
-constexpr int W16_CONV_FRAGS = 3 * KG16_C * KGC * 64;            // fragments (16 B each) per plane
-constexpr int W16_RES_FRAGS = KG16_C * KGC * 64;
-constexpr int W16_BOT_FRAGS = KG16_C * 2 * 64;
-constexpr int W16_CONV_OFF = 0;
-constexpr int W16_RES_OFF = W16_CONV_OFF + 2 * W16_CONV_FRAGS * 16;
-constexpr int W16_BOT_OFF = W16_RES_OFF + 2 * W16_RES_FRAGS * 16;
-constexpr int W16_CST_OFF = W16_BOT_OFF + 2 * W16_BOT_FRAGS * 16;
-constexpr int W16_LAYER_BYTES = W16_CST_OFF + (CST_FLOATS + 32) * 4;
-
-struct Segment16Args {
-    const char* wl;              // [layers][W16_LAYER_BYTES]
-    int l_begin, l_end, n_layers, dil_mid, dil_final;
-    unsigned res_mask;
-    int has_hw;
-    int R, L;
-    const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
-    const float* emb;
-    const float* pe;
-    float* y;
-    const float* pool;
-    float* h;
-    long long h_layer_stride;
-    float* tap;
-    int tap_layer;
-    int n_rows;                  // as in SegmentArgs
-    const int* work;
-    const int* work_count;
-};
-void launch_segment16(const Segment16Args& a, int n_sites, int precision, int max_wgs, hipStream_t s);
-// plain bf16, one workgroup per row, two workgroups resident per CU (dan_kernels_bf16w.hip)
-void launch_segment16w(const Segment16Args& a, int n_sites, hipStream_t s);
 // ---- bf16 "ping-pong" kernel (dan_kernels_bf16p.hip): plain bf16, v_mfma_f32_32x32x16_bf16, two XOR-swizzled LDS images
 // (layer input / layer output), bf16 activations in HBM (y, h), persistent workgroups.  BASELINE config 5 (128 x 301).
 constexpr int P_HALO = 4;                 // zero rows either side of the window (dilation <= 4)
@@ -139,7 +100,8 @@ constexpr int WP_LAYER_BYTES = WP_CST_OFF + (CST_FLOATS + 32) * 4;
 
 struct SegmentPArgs {
     const char* wl;              // [layers][WP_LAYER_BYTES]
-    const char* wlr;             // the same blocks in the sixteen-wave form's fragment order (16x16x32 tiles), or nullptr
+    const char* wlr;             // the same blocks in the sixteen-wave form's fragment order (16x16x32 tiles)
+    int form;                    // 0 = the eight-wave 32x32x16 form (default), 1 = the sixteen-wave 16x16x32 form (dan_config.bf16_form)
     int l_begin, l_end, n_layers, dil_mid, dil_final;
     unsigned res_mask;
     int has_hw;
@@ -158,8 +120,6 @@ struct SegmentPArgs {
     const int* work;
     const int* work_count;
 };
-// true if the structure can run on this kernel (else the eight-wave / two-workgroup kernels take it)
-bool segmentp_supports(int L, int l_begin, unsigned res_mask, bool has_pool);
 void launch_segmentp(const SegmentPArgs& a, int n_sites, int n_cus, hipStream_t s);
 // cp[site][p][o] = sum_{t,c} wpool[o][t * 128 + c] * pool[site][p + (t - 1) dil][c]: the read-mean's share of the convolution
 // behind a pool layer, in fp32 (wpool: that layer's bf16-rounded weights; cols: [n_sites * L][384] scratch; zero_bias: 128 zeros)

@@ -21,7 +21,6 @@
 // Numerics (the oracle's bf16 = "storage" mode, oracle/dan_oracle.py::conv_layer): GEMM operands bf16, sums fp32, bias / ReLU /
 // BatchNorm / residual add in fp32, every stored activation rounded to bf16 (ties to even, v_cvt_pk_bf16_f32).
 #include "dan_kernels.h"
-#include <cstdlib>
 
 namespace dan {
 
@@ -82,15 +81,13 @@ __device__ __forceinline__ unsigned cell_addr(int row, int chunk) { return (unsi
 // A run-time loop over chunks of NA = 4 k-steps: the four weight fragments of the NEXT chunk are requested slot by slot as
 // the current chunk's are consumed (an L2 round trip = 4 x MT MFMAs ahead), the activations of the next k-step while the
 // current one's MFMAs issue (double-buffered registers, one ds_read_b128 behind each MFMA).
-template <int MT, int TAPS, bool FRONT>
+template <int MT, int TAPS>
 __device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8p w,
                                        const bf8 (&first)[4], bool k_short = false) {
     // Fully unrolled over TAPS x 8 k-steps (hipcc then counts its vmcnt waits exactly: a run-time chunk loop drained every
     // outstanding weight fragment once per chunk).  ONE shape serves layer 1 too -- a second conv instance kept a second set of
     // 80 accumulator registers alive -- which leaves the walk early (k_short).
-    // FRONT (the staggered form, where the wave has the SIMD's matrix pipe to itself): the NEXT k-step's activations are all
-    // requested ahead of this step's MFMAs, pinned there by scheduling fences -- a full step of lead for every fragment.
-    // Otherwise (two waves computing side by side cover each other's waits) one read behind each MFMA.
+    // Two waves computing side by side cover each other's waits: one activation read behind each MFMA.
     // NA weight fragments in flight per wave (8 measured the same as 4: the L2 round trip is covered)
 #ifndef DAN_P_NA
 #define DAN_P_NA 4
@@ -114,18 +111,7 @@ __device__ __forceinline__ void gemm_p(v16f (&acc)[MT], const char* lds, unsigne
             if (k_short) break;
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (FRONT) {
-            if (sn < S) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) b[sn & 1][m] = lds_read(lds, xa + m * (32 * P_ROW_BYTES));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma32(a[s % NA], b[s & 1][m], acc[m]);
-            // the slot's next fragment is requested BEHIND the MFMAs that read the slot: it may land in the same registers
-            if (s + NA < S) a[s % NA] = w[(size_t)(s + NA) * 4 * 64];
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
+        {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 acc[m] = mfma32(a[s % NA], b[s & 1][m], acc[m]);
@@ -401,7 +387,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             }
             const unsigned xb0 = cell_addr(row0 - dil, hh), xb1 = cell_addr(row0, hh), xb2 = cell_addr(row0 + dil, hh);
             gbf8p wconv = (gbf8p)(blk + WP_CONV_OFF) + q * 64 + lane;
-            gemm_p<MT, 3, false>(acc, src, xb0, xb1, xb2, wconv, pre_a, l == 0);
+            gemm_p<MT, 3>(acc, src, xb0, xb1, xb2, wconv, pre_a, l == 0);
             PFENCE();
             PSTAMP(sb + 1);
 
@@ -472,7 +458,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                 }
                 gbf8p wres = (gbf8p)(blk + WP_RES_OFF) + q * 64 + lane;
                 PFENCE();
-                gemm_p<MT, 1, false>(acc, dst, xb1, xb1, xb1, wres, pre_a);
+                gemm_p<MT, 1>(acc, dst, xb1, xb1, xb1, wres, pre_a);
                 PFENCE();
                 PSTAMP(sb + 4);
                 load_first(pre_a, (gbf8p)(blk_of(last_layer ? l : l + 1) + WP_CONV_OFF) + q * 64 + lane);
@@ -542,7 +528,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
 }
 
 // ================================================================================================
-// Sixteen-wave form (DAN_BF16_FORM=r): the same two images, stages and barriers as segmentp_kernel, on FOUR waves per SIMD.
+// Sixteen-wave form (dan_config.bf16_form = 1): the same two images, stages and barriers as segmentp_kernel, on FOUR waves per SIMD.
 // v_mfma_f32_16x16x32_bf16: a 16-column tile costs a wave 4 accumulator registers per 16 channels, so a wave of
 // (channel quarter q, position quarter) = 32 channels x PT tiles of 16 columns holds 8 PT accumulators (40 at PT = 5) and the
 // whole wave fits 128 registers.  Why: the lockstep form's SIMDs idle ~25 % of the time with BOTH waves in a wait (L2 round
@@ -966,315 +952,6 @@ __global__ __launch_bounds__(R_THREADS, 1) void segmentr_kernel(SegmentPArgs a) 
     }
 }
 
-// ================================================================================================
-// Staggered form (DAN_BF16_FORM=q; not the default, see launch_segmentp): the two position halves of a read run ONE PHASE APART, so that on every SIMD one wave's MFMA
-// stage (conv / residual GEMM) runs beside the other wave's VALU + LDS stage (epilogue, write-back, copies) instead of both
-// waves computing together and then leaving the matrix pipe idle together (the lockstep form above: ~45 % of a layer).
-//   * each half owns ONE image and updates it IN PLACE; what makes the halves independent inside a segment is a 32-position
-//     tile computed by BOTH (half 0: positions [0, 192), half 1: [128, 320)): a half never reads the other's rows, its results
-//     are exact for the positions it owns ([0, 160) / [160, 320)) as long as the segment's dilations sum to <= 32 -- each layer
-//     invalidates `dilation` more positions of the shared tile from its outer edge.  12 tiles instead of 10: +20 % MFMAs
-//     bought for a pipe that no longer waits for epilogues;
-//   * every stage of a half ends in a workgroup barrier; half 1 passes one extra barrier first and half 0 one at the very end, so
-//     half 1's k-th stage coincides with half 0's (k+1)-th: GEMM | epilogue | [1x1 GEMM | write-back] per layer alternate
-//     matrix and vector work, and the two halves are always in opposite kinds.  No flag, no polling: the hardware barrier
-//     counts waves, not program counters.
-// ================================================================================================
-constexpr int Q_MT = 6;                       // 32-position tiles per half: 5 owned + the shared one
-constexpr int Q_OWN = 5;
-constexpr int Q_SPAN = Q_MT * 32;             // 192 positions
-constexpr int Q_ROWS = Q_SPAN + 2 * P_HALO;   // 200 rows per image
-constexpr int Q_IMG_BYTES = Q_ROWS * P_ROW_BYTES;        // 51 200
-constexpr int Q_CST_OFF = 2 * Q_IMG_BYTES;               // per half: two buffers of 512 floats (this layer's, the next layer's)
-constexpr int Q_LDS_BYTES = Q_CST_OFF + 2 * 2 * 2048;    // 110 592
-
-__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentq_kernel(SegmentPArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[Q_LDS_BYTES];
-    const int tid0 = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int q = wave & 3, half = wave >> 2;
-    const int L = a.L;
-    const int pb = half * (Q_SPAN - 64);                     // first position of this half's image: 0 / 128
-    const int own0 = half;                                   // first owned local tile: half 0 owns tiles 0..4, half 1 tiles 1..5
-    char* const img = lds + half * Q_IMG_BYTES;
-    auto cbuf = [&](int l) { return (float*)(lds + Q_CST_OFF + half * 4096 + (l & 1) * 2048); };
-
-    for (int i = tid0; i < Q_LDS_BYTES / 16; i += SEG_THREADS) *(v4f*)(lds + (size_t)i * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    if (half == 1) __syncthreads();                          // the one-phase stagger (half 0 passes its extra barrier at the end)
-
-    const int n_work = a.work_count ? *a.work_count : a.n_rows;
-    const int slice = a.work_count ? (n_work + 7) / 8 : a.slice_rows;
-    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, nj = gridDim.x >> 3;
-    const bool resumed = a.l_begin > 0;
-
-    for (int k = jw; k < slice; k += nj) {
-        v16f acc[Q_MT];
-        const int wk = xcd * slice + k;
-        if (wk >= n_work) break;
-        const int row_index = __builtin_amdgcn_readfirstlane(a.work_count ? a.work[wk] : wk);
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));                            // (per-lane addresses formed per row, not hoisted and spilled)
-        const int lane = tid & 63, gtid = tid & 255;             // gtid: thread index inside the half
-        const int n = lane & 31, hh = lane >> 5;
-        const int site = row_index / a.R;
-        const size_t read_idx = (size_t)row_index;
-        auto blk_of = [&](int l) { return a.wl + (size_t)l * WP_LAYER_BYTES; };
-        v4f creq;
-        auto cst_request = [&](int l) { if (gtid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WP_CST_OFF) + gtid * 4); };
-        auto cst_put = [&](int l) { if (gtid < 128) *(v4f*)(cbuf(l) + gtid * 4) = creq; };
-        const int c0 = 32 * q + 16 * hh;                          // this lane's 16 output channels
-        const int row0 = P_HALO + n;                              // its row in local tile 0
-        const unsigned wa = cell_addr(row0, 4 * q + 2 * hh);      // its two output chunks: wa, wa ^ 16
-        bf8 pre_a[4];
-
-        [[maybe_unused]] int stamp_i = 1;
-        PSTAMP(0);
-        // ================= stage P: the half's input image
-        cst_request(a.l_begin);
-        load_first(pre_a, (gbf8p)(blk_of(a.l_begin) + WP_CONV_OFF) + q * 64 + lane);
-        if (resumed) {
-            // y (bf16) by LDS-DMA, 1-KiB pieces of 4 rows, swizzle on the per-lane source address; rows outside the window stay zero
-            const char* ysrc = (const char*)(a.y + read_idx * (size_t)L * CPAD);
-            for (int kb = q; kb * 4 < Q_ROWS; kb += 4) {
-                const int r = 4 * kb + (lane >> 4), p = pb - P_HALO + r;
-                if (p >= 0 && p < L) glds16(ysrc + (size_t)p * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
-            }
-            if (a.pool) {                                        // the first layer's accumulator seed: conv(read-mean) of the site
-                const float* cp = a.pool + (size_t)site * (size_t)L * CPAD + c0;
-#pragma unroll
-                for (int m = 0; m < Q_MT; ++m) {
-                    const int p = pb + 32 * m + n;
-                    if (p < L) load16(acc[m], cp + (size_t)p * CPAD);
-                    else acc[m] = (v16f)(0.f);
-                }
-            }
-        } else {
-            // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, rounded to bf16; channels 48..127 zero.  The
-            // allele-agreement predicates span the whole read: every WAVE evaluates them over all L positions for itself
-            const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
-            int ok_ref = 1, ok_var = 1;
-            for (int p = lane; p < L; p += 64) {
-                const int tok = a.reads[rbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
-                ok_ref &= (rm == 0) || (tok == rm);
-                ok_var &= (vm == 0) || (tok == vm);
-            }
-            const int agree_ref = __all(ok_ref), agree_var = __all(ok_var);
-            const int r = gtid, p = pb - P_HALO + r;             // one image row per thread
-            if (r < Q_ROWS && p >= 0 && p < L) {
-                const int tok = a.reads[rbase + p], qv = a.qual[rbase + p], st = a.strand[rbase + p];
-                const int rf = a.ref[sbase + p], rm = a.ref_mask[sbase + p], vm = a.var_mask[sbase + p];
-                const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
-                const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
-                const float* pp = a.pe + p * EMBED;
-                float row[CIN0];
-#pragma unroll
-                for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
-                row[40] = (float)qv * 0.01f;
-                row[41] = (float)st * 0.5f;
-                row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
-                row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
-                row[44] = (rm != 0) ? 1.f : 0.f;
-                row[45] = row[46] = row[47] = 0.f;
-#pragma unroll
-                for (int c = 0; c < CPAD / 8; ++c) {
-                    bf8 v;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (c * 8 + j < CIN0) ? (__bf16)row[(c * 8 + j) % CIN0] : (__bf16)0.f;
-                    lds_write(img, cell_addr(r, c), v);
-                }
-            } else if (r < Q_ROWS) {
-#pragma unroll
-                for (int c = 0; c < CPAD / 8; ++c) lds_write(img, cell_addr(r, c), (bf8)(__bf16)0.f);
-            }
-        }
-        cst_put(a.l_begin);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's DMA pieces (and seeds) have landed
-        { PSTAMP(stamp_i); __syncthreads(); PSTAMP(stamp_i + 1); stamp_i += 2; }
-
-        // owned positions of the image -> fp32 [L][CPAD] (debug tap)
-        auto copy_tap = [&](int nch) {
-            float* dst = a.tap + read_idx * (size_t)L * CPAD;
-            const int p_lo = half ? Q_OWN * 32 : 0, p_hi = half ? L : min(L, Q_OWN * 32);
-            for (int i = gtid + p_lo * 16; i < p_hi * 16; i += 256) {
-                const int p = i >> 4, c = i & 15;
-                const bf8 v = lds_read(img, cell_addr(P_HALO + p - pb, c));
-                v4f o0, o1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { o0[j] = (c * 8 + j < nch) ? (float)v[j] : 0.f; o1[j] = (c * 8 + 4 + j < nch) ? (float)v[4 + j] : 0.f; }
-                *(v4f*)(dst + (size_t)i * 8) = o0;
-                *(v4f*)(dst + (size_t)i * 8 + 4) = o1;
-            }
-        };
-        bf8 wb[P_KSC];
-        v16f bb;
-        auto bottleneck_request = [&](int lb) {
-            gbf8p wbot = (gbf8p)(blk_of(lb) + WP_BOT_OFF) + lane;
-#pragma unroll
-            for (int ks = 0; ks < P_KSC; ++ks) wb[ks] = wbot[ks * 64];
-            load16(bb, (const float*)(blk_of(lb) + WP_CST_OFF) + CST_BBOT + 16 * hh);
-        };
-        // h = relu(Wb y + bb) of layer lb for the half's owned tiles (5 tiles over 4 waves), from the image
-        auto bottleneck_run = [&](int lb) {
-            uint16_t* hrow = a.h + (size_t)lb * a.h_layer_stride + read_idx * (size_t)L * HPAD;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const unsigned xa0 = cell_addr(P_HALO + (ln & 31), ln >> 5);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ot = q + 4 * i;                         // owned tile 0..4
-                if (ot < Q_OWN) {                                 // (uniform)
-                    const char* tile = img + (own0 + ot) * (32 * P_ROW_BYTES);
-                    bf8 bx[P_KSC];
-#pragma unroll
-                    for (int ks = 0; ks < P_KSC; ++ks) bx[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 5));
-                    v16f hacc = bb;
-#pragma unroll
-                    for (int ks = 0; ks < P_KSC; ++ks) hacc = mfma32(wb[ks], bx[ks], hacc);
-                    const int p = pb + 32 * (own0 + ot) + (ln & 31);
-                    if (p < L) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) hacc[j] = relu1(hacc[j]);
-                        bf8 lo, hi;
-                        pack16(hacc, lo, hi);
-                        bf8* o = (bf8*)(hrow + (size_t)p * HPAD + 16 * (ln >> 5));
-                        o[0] = lo;
-                        o[1] = hi;
-                    }
-                }
-            }
-        };
-        // acc[m] (16 channels of one position per lane) -> the half's image, zero past the window
-        auto write_tiles = [&]() {
-#pragma unroll
-            for (int m = 0; m < Q_MT; ++m) {
-                const int p = pb + 32 * m + n;
-                v16f v = acc[m];
-                if (pb + 32 * m + 32 > L) {                      // (uniform) the tile reaches past the window
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
-                }
-                bf8 lo, hi;
-                pack16(v, lo, hi);
-                lds_write(img, wa + m * (32 * P_ROW_BYTES), lo);
-                lds_write(img, (wa ^ 16u) + m * (32 * P_ROW_BYTES), hi);
-            }
-        };
-
-        for (int l = a.l_begin; l < a.l_end; ++l) {
-            const char* blk = blk_of(l);
-            const float* lc = cbuf(l);
-            const bool residual = (a.res_mask >> l) & 1u;
-            const bool last_layer = l + 1 == a.l_end;
-            const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
-            // ================= stage G: [the previous layer's bottleneck] + the conv GEMM
-            PFENCE();
-            if (a.tap && a.tap_layer == l && (l > 0 || !resumed)) copy_tap(l == 0 ? CIN0 : CPAD);
-            if (!last_layer) cst_request(l + 1);
-            if (l == a.l_begin) {                                // (one if / else: on the other path the accumulators are dead and
-                v16f bias;                                        //  their registers serve the bottleneck)
-                lds16(bias, lc + CST_BIAS + c0);
-                if (resumed && a.pool) {
-#pragma unroll
-                    for (int m = 0; m < Q_MT; ++m) acc[m] += bias;
-                } else {
-#pragma unroll
-                    for (int m = 0; m < Q_MT; ++m) acc[m] = bias;
-                }
-            } else {
-                if (a.has_hw) bottleneck_run(l - 1);
-                v16f bias;
-                lds16(bias, lc + CST_BIAS + c0);
-#pragma unroll
-                for (int m = 0; m < Q_MT; ++m) acc[m] = bias;
-            }
-            const unsigned xb0 = cell_addr(row0 - dil, hh), xb1 = cell_addr(row0, hh), xb2 = cell_addr(row0 + dil, hh);
-            __builtin_amdgcn_s_setprio(3);                        // (the SIMD's other wave is in a vector stage: the matrix stream first)
-            gemm_p<Q_MT, 3, false>(acc, img, xb0, xb1, xb2, (gbf8p)(blk + WP_CONV_OFF) + q * 64 + lane, pre_a);
-            __builtin_amdgcn_s_setprio(0);
-            PFENCE();
-            // requests for the stages ahead ride under the barrier
-            load_first(pre_a, (gbf8p)((residual ? blk : blk_of(last_layer ? l : l + 1)) + (residual ? WP_RES_OFF : WP_CONV_OFF)) + q * 64 + lane);
-            { PSTAMP(stamp_i); __syncthreads(); PSTAMP(stamp_i + 1); stamp_i += 2; }
-            // ================= stage E: ReLU, BatchNorm (folded) -> bf16 -> the image, in place; a residual layer first takes its own
-            // cells of the layer input x as the seed (x + bres) of the 1x1 GEMM (model.py:753-761)
-            PFENCE();
-            {
-                v16f sc, sh, br;
-                lds16(sc, lc + CST_SCALE + c0);
-                lds16(sh, lc + CST_SHIFT + c0);
-                if (residual) lds16(br, lc + CST_BRES + c0);
-#pragma unroll
-                for (int m = 0; m < Q_MT; ++m) {
-                    const int p = pb + 32 * m + n;
-                    v16f v = acc[m];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
-                    scale_shift16(v, sc, sh);
-                    if (pb + 32 * m + 32 > L) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = (p < L) ? v[i] : 0.f;
-                    }
-                    if (residual) {
-                        const bf8 xl = lds_read(img, wa + m * (32 * P_ROW_BYTES)), xh = lds_read(img, (wa ^ 16u) + m * (32 * P_ROW_BYTES));
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { acc[m][j] = (float)xl[j] + br[j]; acc[m][8 + j] = (float)xh[j] + br[8 + j]; }
-                    }
-                    bf8 lo, hi;
-                    pack16(v, lo, hi);
-                    lds_write(img, wa + m * (32 * P_ROW_BYTES), lo);
-                    lds_write(img, (wa ^ 16u) + m * (32 * P_ROW_BYTES), hi);
-                }
-            }
-            if (!last_layer) cst_put(l + 1);
-            PFENCE();
-            // (behind the epilogue, which cannot spare the 48 registers -- and on EVERY path through the layer: requested under a
-            // condition, hipcc keeps the previous request's registers alive through the whole GEMM for the path that skips this one)
-            bottleneck_request(l);
-            { PSTAMP(stamp_i); __syncthreads(); PSTAMP(stamp_i + 1); stamp_i += 2; }
-            if (residual) {
-                // ================= stage R: y = Wr t + (x + bres), t = the image
-                const unsigned xr = cell_addr(row0, hh);
-                __builtin_amdgcn_s_setprio(3);
-                gemm_p<Q_MT, 1, false>(acc, img, xr, xr, xr, (gbf8p)(blk + WP_RES_OFF) + q * 64 + lane, pre_a);
-                __builtin_amdgcn_s_setprio(0);
-                PFENCE();
-                load_first(pre_a, (gbf8p)(blk_of(last_layer ? l : l + 1) + WP_CONV_OFF) + q * 64 + lane);
-                { PSTAMP(stamp_i); __syncthreads(); PSTAMP(stamp_i + 1); stamp_i += 2; }
-                // ================= stage W: y -> the image
-                PFENCE();
-                write_tiles();
-                PFENCE();
-                { PSTAMP(stamp_i); __syncthreads(); PSTAMP(stamp_i + 1); stamp_i += 2; }
-            }
-        }
-        // ================= stage T: the last layer's bottleneck, the owned positions -> y
-        if (a.tap && a.tap_layer == a.l_end) copy_tap(CPAD);
-        if (a.has_hw) bottleneck_run(a.l_end - 1);
-        {
-            bf8* ydst = (bf8*)(a.y + read_idx * (size_t)L * CPAD);
-            const int p_lo = half ? Q_OWN * 32 : 0, p_hi = half ? L : min(L, Q_OWN * 32);
-            for (int i = gtid + p_lo * 16; i < p_hi * 16; i += 256) ydst[i] = lds_read(img, cell_addr(P_HALO + (i >> 4) - pb, i & 15));
-        }
-        { PSTAMP(stamp_i); __syncthreads(); PSTAMP(stamp_i + 1); stamp_i += 2; }
-    }
-    if (half == 0) __syncthreads();                          // (the barrier half 1 passed first)
-}
-
-bool segmentp_supports(int L, int l_begin, unsigned res_mask, bool has_pool) {
-    if (L > P_LMAX) return false;
-    // a residual layer that opens a resumed segment takes its residual from y BEFORE the pool add (model.py:732 vs :742); this
-    // kernel seeds the residual from the LDS image, which there holds y + pool
-    if (l_begin > 0 && has_pool && ((res_mask >> l_begin) & 1u)) return false;
-    return true;
-}
-
-static bool staggered_ok(const SegmentPArgs& a) {
-    int sum = 0;
-    for (int l = a.l_begin; l < a.l_end; ++l) sum += (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
-    return sum <= 32 && a.L > Q_OWN * 32;                     // the shared tile absorbs the segment's halo growth; both halves own columns
-}
-
 void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t s) {
     SegmentPArgs a = a0;
     a.n_rows = n_sites * a.R;
@@ -1283,18 +960,16 @@ void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t
     wgs = (wgs + 7) / 8 * 8;
     const int need = ((a.slice_rows + 0) < 1 ? 1 : a.slice_rows) * 8;       // no more workgroups than rows per slice x 8
     if (wgs > need) wgs = need;
-    // DAN_BF16_FORM=q selects the staggered form (measured SLOWER, 18.0 k vs 20.5 k sites/s on config 5; kept for A/B runs).  Its
-    // premise does not hold on this hardware: a vector instruction of the SIMD's OTHER wave delays this wave's MFMA walk by its
-    // full ~3.7 cycles, at any s_setprio (tools/ubench/gemm_p_lone.hip: 37.8 cycles per MFMA beside a parked partner, 46 / 56 / 70
-    // beside 300 / 600 / 1000 vector instructions) -- an epilogue beside a GEMM costs what it costs behind it, and the form pays
-    // 20 % of redundant tiles on top.  DESIGN.md section 11.1.
-    const char* form_env = getenv("DAN_BF16_FORM");
-    if (a.wlr && form_env && form_env[0] == 'r') {
+    // form 1: the sixteen-wave form (16x16x32 tiles, four waves per SIMD) -- an independently written second implementation held to
+    // the same layer-by-layer oracle tests; measured 7 % slower end to end (the chip clocks the denser form lower: DESIGN.md 11.1).
+    // (Round 3 also carried a staggered form -- position halves one phase apart -- measured 12 % slower and deleted in round 4: a vector
+    // instruction of the SIMD's other wave delays an MFMA walk by its full issue time, so an epilogue beside a GEMM costs what it costs
+    // behind it, and that form paid 20 % of redundant tiles on top.)
+    if (a.form == 1) {
         if (a.L <= 4 * 3 * 16) hipLaunchKernelGGL((segmentr_kernel<3>), dim3((unsigned)wgs), dim3(R_THREADS), 0, s, a);
         else if (a.L <= 4 * 4 * 16) hipLaunchKernelGGL((segmentr_kernel<4>), dim3((unsigned)wgs), dim3(R_THREADS), 0, s, a);
         else hipLaunchKernelGGL((segmentr_kernel<5>), dim3((unsigned)wgs), dim3(R_THREADS), 0, s, a);
-    } else if (staggered_ok(a) && form_env && form_env[0] == 'q')
-        hipLaunchKernelGGL(segmentq_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    }
     // each position half owns MT tiles of 32 columns: the narrowest tiling that covers the window (201 columns on 2 x 5 tiles
     // would spend 37 % of the MFMAs past column 201; 2 x 4 tiles 22 %)
     else if (a.L <= 2 * 3 * 32)

@@ -21,8 +21,8 @@ extern "C" {
 #endif
 
 /* ABI history: 1 = first release; 2 = dan_config.conv_algo; 3 = dan_config.skip_empty_rows (struct grows at the end);
- * 4 = dan_forward_async / dan_wait. */
-#define DAN_ABI_VERSION 4
+ * 4 = dan_forward_async / dan_wait; 5 = dan_config.bf16_form (the library reads no environment variable any more). */
+#define DAN_ABI_VERSION 5
 #define DAN_MAX_LAYERS 16
 
 typedef enum dan_status {
@@ -57,7 +57,8 @@ typedef struct dan_config {
                                * product, L <= 208); 2 = plain bf16 (L <= 304, BASELINE config 5)   */
     int32_t device_id;        /* HIP device ordinal                                               */
     int32_t max_batch;        /* sites per FC macro-batch (0 = 4096)                              */
-    int32_t chunk_sites;      /* sites per conv-stack chunk (0 = largest power of two with y + h under 48 GB) */
+    int32_t chunk_sites;      /* sites per conv-stack chunk (0 = largest power of two whose y + h fit 48 GB and a third of the
+                               * device memory that is free at dan_create) */
     int32_t conv_algo;        /* fp32 path, form of the 3-tap convolutions after the first layer: 1 = direct implicit
                                * GEMM; 2 = Winograd F(2,3) over the dilated positions (needs every such layer to
                                * have dilation 2: 4 exact-fp32 GEMMs per 2 outputs instead of 6); 0 = Winograd
@@ -66,6 +67,9 @@ typedef struct dan_config {
                                * the rows below the site's coverage) once per site and let every other such row use
                                * that result -- their encoded input is identical, so every output is bit-identical to
                                * computing all rows (which is what 0 does, and what the reference does)              */
+    int32_t bf16_form;        /* precision 2, form of the conv-stack kernel: 0 = eight waves, 32x32x16 tiles (default);
+                               * 1 = sixteen waves, 16x16x32 tiles -- a second, independently written implementation of the
+                               * same arithmetic that the parity tests hold to the same oracle (~7 % slower)            */
 } dan_config;
 
 typedef struct dan_handle dan_t;

@@ -68,8 +68,8 @@ def test_abi_version(lib):
 
 
 def test_config_struct_layout():
-    # 22 x 4-byte fields, no padding: must match struct dan_config in the header
-    assert ctypes.sizeof(capi.DanCConfig) == 4 * 22
+    # 23 x 4-byte fields, no padding: must match struct dan_config in the header
+    assert ctypes.sizeof(capi.DanCConfig) == 4 * 23
     cc = capi.c_config(production_config(reads=64), device_id=3)
     assert (cc.reads, cc.length, cc.layers, cc.device_id) == (64, 201, 7, 3)
     assert cc.pool_layers_mask == 1 << 2 and list(cc.fc_sizes) == [1024, 256]
@@ -78,7 +78,7 @@ def test_config_struct_layout():
 def test_header_struct_fields_match_binding():
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     body = re.search(r"typedef struct dan_config \{(.*?)\} dan_config;", text, flags=re.S).group(1)
-    names = re.findall(r"u?int32_t\s+([a-z_]+)(?:\[\d+\])?\s*;", body)
+    names = re.findall(r"u?int32_t\s+([a-z0-9_]+)(?:\[\d+\])?\s*;", body)
     assert names == [f[0] for f in capi.DanCConfig._fields_]
 
 
@@ -92,6 +92,19 @@ def test_create_rejects_bad_config_without_touching_the_gpu(lib):
     cc = capi.c_config(DanConfig(reads=8, dil_mid=3, conv_algo=2), 0)      # Winograd form needs dilation 2
     assert lib.dan_create(ctypes.byref(cc), ctypes.byref(h)) == -1
     assert b"dilation 2" in lib.dan_last_error(None)
+
+
+def test_the_library_reads_no_environment_variable():
+    """kernel forms are chosen through dan_config (bf16_form), not through the process environment."""
+    src = os.path.join(ROOT, "dl4vc_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".cpp", ".h")) and not name.startswith(("dan_loader", "dan_pileup")):
+            assert "getenv" not in open(os.path.join(src, name)).read(), name
+    h = ctypes.c_void_p()
+    cc = capi.c_config(DanConfig(reads=8), 0)
+    cc.bf16_form = 1                       # a form of the precision-2 kernel only
+    lib_ = capi.load_library()
+    assert lib_.dan_create(ctypes.byref(cc), ctypes.byref(h)) == -1 and b"bf16_form" in lib_.dan_last_error(None)
 
 
 def test_no_gpu_means_loud_failure(lib):

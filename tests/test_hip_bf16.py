@@ -149,40 +149,41 @@ def test_fp32_rejects_long_window_but_bf16_accepts():
     DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16)).close()
 
 
-@pytest.mark.parametrize("case", ["dan_small", "dan_var_pool24", "dan_var_l5res2", "dan_var_cfinal", "dan_var_nohw", "dan_var_nobn"])
-def test_plain_bf16_two_workgroup_form_is_bit_identical_to_the_eight_wave_form(case, monkeypatch):
-    """precision 2 runs dan_kernels_bf16w.hip (four waves, two workgroups per CU, two channel passes) when every row is computed;
-    DAN_BF16_FORM=8 selects the eight-wave kernel.  Same arithmetic in the same order: every output bit agrees, on the
-    structural variants (pool layers, a residual layer opening a segment, c_final != c_init, no highway, no BatchNorm)."""
+@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("case", model_cases())
+def test_plain_bf16_structures_against_the_storage_mode_oracle(case, form):
+    """precision 2 has ONE kernel family since round 4 (dan_kernels_bf16p.hip; the eight-wave / two-workgroup kernels of rounds
+    1-2 are gone), so every structure the golden set holds runs on it: pool layers [2,4], a residual layer that OPENS a resumed
+    segment (l5res2: its residual is y before the read-mean is added -- the image the kernel DMAs -- model.py:732 vs :742),
+    c_final != c_init, no highway, no BatchNorm, other dilations.  Held to the oracle's bf16 = "storage" mode (the kernel's
+    specification, pinned through the "operands" mode by tests/golden/bf16_operands_*.npz): two correct bf16 evaluations differ by
+    rounding decisions that cascade, so the bar is a bf16-sized one on the logits (the layer-by-layer 2-ulp bars are
+    tests/test_hip_bf16_config5.py's) -- and the same bar against the reference's fp32 fixture.  Both kernel forms."""
     spec, w, inp, out = load_case(case)
-    res = {}
-    for form in ("4", "8"):
-        monkeypatch.setenv("DAN_BF16_FORM", form)
-        net = DanNet(_cfg(spec, PRECISION_BF16)).load_state_dict(w)
-        res[form] = net.forward_u8(*input_tuple(inp), aux=True)
-        net.close()
-    for k in res["4"]:
-        assert np.array_equal(res["4"][k], res["8"][k]), (case, k)
+    cfg = _cfg(spec, PRECISION_BF16)
+    import dataclasses
+    net = DanNet(dataclasses.replace(cfg, bf16_form=form)).load_state_dict(w)
+    assert net.handle.query("bf16_pingpong") == 1
+    got = net.forward_u8(*input_tuple(inp), aux=True)
+    net.close()
+    want = dan_forward_oracle(w, spec, *input_tuple(inp), bf16="storage")
     scale = max(1.0, float(np.abs(out["vt_logits"]).max()))
-    assert np.abs(res["4"]["vt_logits"] - out["vt_logits"]).max() < 0.05 * scale
+    assert np.isfinite(got["vt_logits"]).all()
+    assert np.abs(got["vt_logits"] - want["vt_logits"]).max() < 0.02 * scale, case
+    assert np.abs(got["vt_logits"] - out["vt_logits"]).max() < 0.05 * scale, case
+    assert np.abs(got["vt_prob"] - want["vt_prob"]).max() < 0.02
 
 
-def test_plain_bf16_forms_agree_at_301_columns_and_with_empty_row_skipping(monkeypatch):
+def test_plain_bf16_301_columns_with_empty_row_skipping():
     cfg = DanConfig(reads=20, length=301, precision=PRECISION_BF16)
     sd = random_state_dict(cfg, seed=5)
     batch = synth.make_sites(5, reads=20, length=301, seed=6)
-    res = {}
-    for form in ("4", "8"):
-        monkeypatch.setenv("DAN_BF16_FORM", form)
-        net = DanNet(cfg).load_state_dict(sd)
-        res[form] = net.forward_u8(*batch.arrays(), aux=True)
-        net.close()
-    for k in res["4"]:
-        assert np.array_equal(res["4"][k], res["8"][k]), k
+    net = DanNet(cfg).load_state_dict(sd)
+    res = net.forward_u8(*batch.arrays(), aux=True)
+    net.close()
     import dataclasses
-    monkeypatch.setenv("DAN_BF16_FORM", "4")
-    net = DanNet(dataclasses.replace(cfg, skip_empty_rows=True)).load_state_dict(sd)      # (the row-list forms stay on the eight-wave kernel)
+    net = DanNet(dataclasses.replace(cfg, skip_empty_rows=True)).load_state_dict(sd)
     skip = net.forward_u8(*batch.arrays(), aux=True)
     net.close()
     for k in skip:
-        assert np.array_equal(skip[k], res["4"][k]), k
+        assert np.array_equal(skip[k], res[k]), k

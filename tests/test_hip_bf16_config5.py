@@ -70,7 +70,7 @@ def _compare(got, want, what, min_identical=0.97, upstream=0.0):
     return frac
 
 
-# kernel form: "p" = the default eight-wave lockstep form, "r" = the sixteen-wave 16x16x32 form (DAN_BF16_FORM=r); both are held to
+# kernel form: "p" = the default eight-wave lockstep form, "r" = the sixteen-wave 16x16x32 form (dan_config.bf16_form = 1); both are held to
 # the oracle layer by layer (their fp32 summation orders differ, so they are not bit-identical to each other)
 RUNS = [(r, l, "p") for r, l in SHAPES] + [(r, l, "r") for r, l in SHAPES]
 FORM = {"value": "p"}
@@ -78,25 +78,13 @@ FORM = {"value": "p"}
 
 @pytest.fixture(scope="module", params=RUNS, ids=lambda x: "%dx%d-%s" % x)
 def run(request):
-    import os
     R, L, form = request.param
     FORM["value"] = form
-    old_env = os.environ.get("DAN_BF16_FORM")
-    if form == "p":
-        os.environ.pop("DAN_BF16_FORM", None)
-    else:
-        os.environ["DAN_BF16_FORM"] = form
-    try:
-        yield _run(R, L)
-    finally:
-        if old_env is None:
-            os.environ.pop("DAN_BF16_FORM", None)
-        else:
-            os.environ["DAN_BF16_FORM"] = old_env
+    yield _run(R, L, form)
 
 
-def _run(R, L):
-    cfg = DanConfig(reads=R, length=L, precision=PRECISION_BF16)
+def _run(R, L, form="p"):
+    cfg = DanConfig(reads=R, length=L, precision=PRECISION_BF16, bf16_form=int(form == "r"))
     sd = random_state_dict(cfg, seed=3)
     planes = _sites(R, L)
     net = DanNet(cfg).load_state_dict(sd)
@@ -217,23 +205,3 @@ def test_chunking_and_empty_row_skipping_leave_every_bit_unchanged(run):
         assert np.array_equal(got[k], out[k]), k
 
 
-def test_staggered_form_is_bit_identical_to_the_lockstep_form(run, monkeypatch):
-    """DAN_BF16_FORM=q runs the staggered form of the kernel (position halves one phase apart, each updating its own image in
-    place, a 32-column tile computed by both): the same sums in the same order for every column a half owns -- every output bit
-    agrees with the default lockstep form.  (Also a check of the halo bookkeeping: a column of the shared tile used one layer
-    too long would differ.)"""
-    cfg, sd, planes, taps, pool, hbuf, feat, out = run
-    if FORM["value"] != "p":
-        pytest.skip("the staggered form repeats the lockstep form's sums, not the sixteen-wave form's")
-    monkeypatch.setenv("DAN_BF16_FORM", "q")
-    net = DanNet(cfg).load_state_dict(sd)
-    assert net.handle.query("bf16_pingpong") == 1
-    got = net.forward_u8(*planes, aux=True)
-    net.handle.set_tap(cfg.layers)
-    net.forward_u8(*planes)
-    B, R, L = planes[0].shape
-    tap7 = net.handle.read_buffer("tap", B * R * L * 128).reshape(B, R, L, 128)
-    net.close()
-    assert np.array_equal(tap7, taps[cfg.layers])
-    for k in out:
-        assert np.array_equal(got[k], out[k]), k

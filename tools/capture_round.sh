@@ -28,8 +28,8 @@ timeout -k 10 400 tools/profile_pmc.sh "pmc_bf16_$tag" --precision 2 --reads 128
 timeout -k 10 400 tools/profile_pmc.sh "pmc_train_$tag" --mode train --steps 2 --warmup 1 --no-cpu-baseline
 # stamped diagnostic build of the bf16 segment kernel and the GEMM-walk microbenchmarks (built here: binaries are not committed)
 hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/segp_probe.hip -o /tmp/segp_probe.bin 2> /dev/null
-DAN_BF16_FORM=p timeout -k 10 60 /tmp/segp_probe.bin 0 2 301 > "$out/segp_probe_segment1.txt" 2>&1
-DAN_BF16_FORM=p timeout -k 10 60 /tmp/segp_probe.bin 2 7 301 > "$out/segp_probe_segment2.txt" 2>&1
+timeout -k 10 60 /tmp/segp_probe.bin 0 2 301 > "$out/segp_probe_segment1.txt" 2>&1
+timeout -k 10 60 /tmp/segp_probe.bin 2 7 301 > "$out/segp_probe_segment2.txt" 2>&1
 hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_bf16_feed.hip -o /tmp/mfma_bf16_feed.bin 2> /dev/null
 hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_alone.hip -o /tmp/gemm_p_alone.bin 2> /dev/null
 hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_lone.hip -o /tmp/gemm_p_lone.bin 2> /dev/null

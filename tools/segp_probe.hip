@@ -44,7 +44,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), &d_st, sizeof d_st));
 #endif
     SegmentPArgs a{};
-    a.wl = d_wl; a.wlr = d_wl; a.l_begin = l_begin; a.l_end = l_end; a.n_layers = layers; a.dil_mid = 2; a.dil_final = 2;
+    a.wl = d_wl; a.wlr = d_wl; a.form = argc > 4 ? atoi(argv[4]) : 0;   // [form]: 1 = the sixteen-wave form
+     a.l_begin = l_begin; a.l_end = l_end; a.n_layers = layers; a.dil_mid = 2; a.dil_final = 2;
     a.res_mask = 0x70; a.has_hw = 1; a.R = R; a.L = L;
     a.reads = a.qual = a.strand = a.ref = a.ref_mask = a.var_mask = d_u8;
     a.emb = d_emb; a.pe = d_pe; a.y = d_y; a.pool = l_begin ? d_pool : nullptr; a.h = d_h; a.h_layer_stride = (long long)hls;
@@ -73,16 +74,6 @@ int main(int argc, char** argv) {
         std::sort(d.begin(), d.end());
         return d[d.size() / 2];
     };
-    if (!(getenv("DAN_BF16_FORM") && (getenv("DAN_BF16_FORM")[0] == 'p' || getenv("DAN_BF16_FORM")[0] == 'r'))) {
-        // staggered form: stamps 0, then (end of stage, start of next stage) pairs around every barrier
-        printf("staggered form, segment [%d,%d) L=%d: median cycles per stage of the third row, half 0 | half 1  (stage work, then its barrier wait)\n", l_begin, l_end, L);
-        for (int k = 0; k + 2 < 64; k += 2) {
-            const long long w0 = med(k, k + 1, 0), w1 = med(k, k + 1, 4), b0 = med(k + 1, k + 2, 0), b1 = med(k + 1, k + 2, 4);
-            if (w0 < 0 && w1 < 0) break;
-            printf("stage %2d: work %7lld | %7lld   barrier wait %7lld | %7lld\n", k / 2, w0, w1, b0, b1);
-        }
-        return 0;
-    }
     printf("segment [%d,%d) L=%d  median cycles of the third row of every workgroup\n", l_begin, l_end, L);
     printf("prologue                    %8lld   (requests issued %lld | data arrived %lld | converted + stored + barrier %lld)\n", med(0, 1, -1),
            med(0, 60, -1), med(60, 61, -1), med(61, 1, -1));
