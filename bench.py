@@ -475,6 +475,8 @@ def main():
             traffic = pmc_traffic("segment_kernel_bytes_per_launch", "total")
         elif not args.chunk_sites and cfg.reads == 128 and cfg.precision == 2 and cfg.length == 301:
             traffic = pmc_traffic("segmentp_kernel_bytes_per_launch", "total")
+        elif not args.chunk_sites and cfg.reads == 64 and cfg.precision == 1 and cfg.length == 201:
+            traffic = pmc_traffic("segmentx_kernel_bytes_per_launch", "total")
         sites_total = B * world * args.steps
         value = sites_total / elapsed
         # roofline of the dominant kernel (conv-stack segment kernel): algorithmic FLOPs = 2 x MAC of every

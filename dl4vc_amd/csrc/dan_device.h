@@ -158,11 +158,29 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // a - b as two v_pk_fma_f32 (b * m1 + a with m1 = -1.0 in a register the compiler cannot see through: hipcc turns a
 // v2f32 fsub, or an fma by a literal -1, into two scalar v_sub_f32; every VALU instruction costs the SIMD 3-5 cycles of
 // MFMA issue -- tools/ubench/mfma_valu.hip -- so the packed form halves the price of the input transform)
+#ifdef DAN_WINO_UNPACKED
+// A/B build (VERDICT r3 item 4a, MI355X_MICROARCH.md "packed f32 VALU beside MFMAs is an anti-lever"): the same transform as
+// sixteen one-float instructions per tile.  As inline assembly, or hipcc's SLP pass packs them again.  Measured: see DESIGN.md.
+__device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f) {
+    v4f r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float t; asm("v_sub_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(b[i])); r[i] = t; }
+    return r;
+}
+__device__ __forceinline__ v4f pk_add(v4f a, v4f b) {
+    v4f r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float t; asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(b[i])); r[i] = t; }
+    return r;
+}
+#else
 __device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
     const v2f lo = __builtin_elementwise_fma((v2f){b[0], b[1]}, m1, (v2f){a[0], a[1]});
     const v2f hi = __builtin_elementwise_fma((v2f){b[2], b[3]}, m1, (v2f){a[2], a[3]});
     return (v4f){lo[0], lo[1], hi[0], hi[1]};
 }
+__device__ __forceinline__ v4f pk_add(v4f a, v4f b) { return a + b; }
+#endif
 __device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
     v4f a_nxt[4];
 #pragma unroll
@@ -184,7 +202,7 @@ __device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* x
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             v4f v[4];
-            v[0] = pk_sub(xa, xc, m1); v[1] = xb + xc; v[2] = pk_sub(xc, xb, m1); v[3] = pk_sub(xb, xd, m1);
+            v[0] = pk_sub(xa, xc, m1); v[1] = pk_add(xb, xc); v[2] = pk_sub(xc, xb, m1); v[3] = pk_sub(xb, xd, m1);
             if (m + 1 < MW) {
                 xa = xc; xb = xd;
                 xc = *(const v4f*)(xg + (4 * m + 8) * LDS_S);

@@ -208,6 +208,12 @@ void launch_highway(const float* h, long long h_layer_stride, const float* wc_pa
 // ws (may be null): ws_floats >= 2 M N lets a long-k product with few tiles split its k range over two co-resident workgroups
 void launch_fc(const float* A, long long lda, const float* W, long long ldw, const float* bias, float* C,
                long long ldc, int M, int N, int K, int relu, hipStream_t s, float* ws = nullptr, long long ws_floats = 0);
+// the fixed-order sum of launch_fc's split-k partial sums (+ bias, ReLU): ws [parts][M][N] -> C
+void launch_fc_combine(const float* ws, int parts, const float* bias, float* C, long long ldc, int M, int N, int relu, hipStream_t s);
+// the same product on the bf16 matrix cores with split operands (dan_kernels_bf16x.hip; precision >= 1): W as two bf16 planes
+// [2][N][ldw] (hi = bf16(w), lo = bf16(w - hi); w_plane = elements between the planes), A split on the fly, three MFMAs per product
+void launch_fcx(const float* A, long long lda, const uint16_t* W, long long ldw, long long w_plane, const float* bias, float* C,
+                long long ldc, int M, int N, int K, int relu, hipStream_t s, float* ws = nullptr, long long ws_floats = 0);
 // heads + softmax: hidden [B][hid] -> logits/probabilities   (model.py:919-958, trainer.py:609-623)
 void launch_heads(const float* hidden, int hid, const float* wh /*[NHEAD][hid]*/, const float* bh, int B,
                   float* bin_logits, float* vt_logits, float* vt_prob, float* bp, float* aux, hipStream_t s);

@@ -906,10 +906,12 @@ void launch_fc(const float* A, long long lda, const float* W, long long ldw, con
     const int ksplit = (ws && ws_floats >= 2LL * M * N && K >= 64 * FC_BK && n_tiles <= 384) ? 2 : 1;
     const int grid = ((n_tiles * ksplit + 7) / 8) * 8;
     hipLaunchKernelGGL(fc_kernel, dim3(grid), dim3(FC_THREADS), 0, s, A, lda, W, ldw, bias, C, ldc, M, N, K, relu, tiles_n, n_tiles, ksplit, ws);
-    if (ksplit > 1) {
-        const long long total = (long long)M * N;
-        hipLaunchKernelGGL(fc_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, ksplit, bias, C, ldc, M, N, relu);
-    }
+    if (ksplit > 1) launch_fc_combine(ws, ksplit, bias, C, ldc, M, N, relu, s);
+}
+
+void launch_fc_combine(const float* ws, int parts, const float* bias, float* C, long long ldc, int M, int N, int relu, hipStream_t s) {
+    const long long total = (long long)M * N;
+    hipLaunchKernelGGL(fc_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, parts, bias, C, ldc, M, N, relu);
 }
 
 // ------------------------------------------------------------------------------------------------

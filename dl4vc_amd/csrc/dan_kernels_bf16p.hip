@@ -148,37 +148,49 @@ __device__ __forceinline__ void pack16(const v16f& v, bf8& lo, bf8& hi) {
     for (int j = 0; j < 8; ++j) { lo[j] = (__bf16)v[j]; hi[j] = (__bf16)v[8 + j]; }
 }
 
-// h = relu(Wb * y + bb), 128 -> 32 (model.py:774) from image `img`, position tiles of 32 dealt over waves 0 .. NW-1; every
-// activation fragment of the wave's tiles is requested before the first MFMA (the conv accumulators are dead here: registers
-// are plentiful), the tiles' chains interleave.  wb, bb: the layer's eight weight fragments and this lane's 16 biases (requested
-// by the caller a stage ahead).
+// h = relu(Wb * y + bb), 128 -> 32 (model.py:774) from image `img`, position tiles of 32 dealt over waves 0 .. NW-1.
+//   a: the layer's eight weight fragments, one per 16-channel k-step, bb: this lane's 16 biases -- requested by the caller a stage
+//   ahead (streamed inside the stage, two steps ahead, every second step waited an L2 round trip: 5.6 k cycles for 24 MFMAs).
+// Channel-group major (round 4; the sums per output keep their order: bit-identical to the tile-major form): a k-step's ONE
+// weight fragment serves all of the wave's tiles, the activation fragments of the next three (step, tile) pairs are in flight
+// under the current MFMA -- 16 NTL accumulators + 16 registers of activations, where the tile-major form held two tiles'
+// fragments (64 registers) and could not run beside live conv accumulators.
+// NW = 8: a stage of its own (the segment's last layer).  NW = 4: the deferred form -- the SIMD arbiter serves the older wave
+// first, so waves 0-3 leave the conv GEMM well before waves 4-7 and would wait at the barrier: they run the PREVIOUS layer's
+// bottleneck in that wait, from the image the GEMM has just read (as the fp32 and bf16x3 kernels do).
 template <int MT, int NW>
-__device__ __forceinline__ void bottleneck_p(const char* img, const bf8 (&wb)[P_KSC], const v16f& bb, uint16_t* hrow, int L,
-                                             int wave, int lane) {
-    constexpr int NTL = (2 * MT + NW - 1) / NW;
+__device__ __forceinline__ void bottleneck_ps(const char* img, const bf8 (&a)[P_KSC], const v16f& bb, uint16_t* hrow, int L, int wave, int lane) {
+    constexpr int NT = 2 * MT, NTL = (NT + NW - 1) / NW, N = P_KSC * NTL;
     asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop: they spilled)
     const int n = lane & 31, hh = lane >> 5;
     const unsigned xa0 = cell_addr(P_HALO + n, hh);              // 32 rows further on the swizzle repeats: tile tl lies tl * 8 KiB on
-    bf8 bx[2][P_KSC];                                            // the next tile's fragments are requested under this tile's MFMAs
-    auto fetch = [&](int i, bf8 (&dst)[P_KSC]) {
-        const int tl = min(wave + NW * i, 2 * MT - 1);
-        const char* tile = img + tl * (32 * P_ROW_BYTES);
+    const int nt_live = min(NT, (L + 31) >> 5);                  // tiles that hold window columns (an index past them is clamped)
+    constexpr int RB = 4;                                        // activation fragments in flight: an MFMA is 32 cycles, an LDS round trip > 100
+    bf8 bx[RB];
+    v16f hacc[NTL];
 #pragma unroll
-        for (int ks = 0; ks < P_KSC; ++ks) dst[ks] = lds_read(tile, xa0 ^ (unsigned)(ks << 5));
+    for (int i = 0; i < NTL; ++i) hacc[i] = bb;
+    auto xaddr = [&](int k) {                                    // k = ks * NTL + i
+        const int ks = k / NTL, i = k % NTL;
+        return (unsigned)(min(wave + NW * i, nt_live - 1) * (32 * P_ROW_BYTES)) + (xa0 ^ (unsigned)(ks << 5));
     };
-    fetch(0, bx[0]);
+#pragma unroll
+    for (int k = 0; k < RB - 1 && k < N; ++k) bx[k] = lds_read(img, xaddr(k));
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int ks = k / NTL, i = k % NTL;
+        if (k + RB - 1 < N) bx[(k + RB - 1) % RB] = lds_read(img, xaddr(k + RB - 1));
+        hacc[i] = mfma32(a[ks], bx[k % RB], hacc[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
-        if (i + 1 < NTL) fetch(i + 1, bx[(i + 1) & 1]);
-        v16f hacc = bb;
-#pragma unroll
-        for (int ks = 0; ks < P_KSC; ++ks) hacc = mfma32(wb[ks], bx[i & 1][ks], hacc);
         const int tl = wave + NW * i, p = 32 * tl + n;
-        if (tl < 2 * MT && p < L) {
+        if (tl < NT && p < L) {
+            v16f hv = hacc[i];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) hacc[j] = relu1(hacc[j]);
+            for (int j = 0; j < 16; ++j) hv[j] = relu1(hv[j]);
             bf8 lo, hi;
-            pack16(hacc, lo, hi);
+            pack16(hv, lo, hi);
             bf8* o = (bf8*)(hrow + (size_t)p * HPAD + 16 * hh);
             o[0] = lo;
             o[1] = hi;
@@ -365,7 +377,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             const float* lc = cbuf(l);
             const bool residual = (a.res_mask >> l) & 1u;
             const bool last_layer = l + 1 == a.l_end;
-            const bool defer = a.has_hw && l > a.l_begin;          // layer l-1's bottleneck runs behind this layer's epilogue
+            // layer l-1's bottleneck runs behind this layer's GEMM on the four older waves, in their wait at the barrier
+            const bool defer = a.has_hw && l > a.l_begin && wave < NWAVE / 2;
             const int dil = (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final);
             const char* src = lds + cur * P_IMG_BYTES;
             char* dst = lds + (cur ^ 1) * P_IMG_BYTES;
@@ -373,6 +386,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             PSTAMP(sb + 0);
             PFENCE();
             if (!last_layer) cst_request(l + 1);
+            // the deferred bottleneck's operands (layer l-1, older waves): requested here, they arrive under the conv GEMM
+            bf8 wbq[P_KSC];
+            v16f bbq;
+            auto bottleneck_request = [&](int lb) {
+                gbf8p wbot = (gbf8p)(blk_of(lb) + WP_BOT_OFF) + lane;
+#pragma unroll
+                for (int ks = 0; ks < P_KSC; ++ks) wbq[ks] = wbot[ks * 64];
+                load16(bbq, (const float*)(blk_of(lb) + WP_CST_OFF) + CST_BBOT + 16 * hh);
+            };
+            if (defer) bottleneck_request(l - 1);
 
             {
                 v16f bias;
@@ -391,21 +414,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             PFENCE();
             PSTAMP(sb + 1);
 
+            if (defer) bottleneck_ps<MT, NWAVE / 2>(src, wbq, bbq, a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            PFENCE();
+            PSTAMP(sb + 7);
             // ---- epilogue: ReLU, BatchNorm (folded), rows past the window forced to zero, bf16, two 16-byte stores per tile
-            bf8 wb[P_KSC];
-            v16f bb;
-            auto bottleneck_request = [&](int lb) {              // layer lb's bottleneck weights and this lane's biases
-                gbf8p wbot = (gbf8p)(blk_of(lb) + WP_BOT_OFF) + lane;
-#pragma unroll
-                for (int ks = 0; ks < P_KSC; ++ks) wb[ks] = wbot[ks * 64];
-                load16(bb, (const float*)(blk_of(lb) + WP_CST_OFF) + CST_BBOT + 16 * hh);
-            };
             {
                 v16f sc, sh;
                 lds16(sc, lc + CST_SCALE + c0);
                 lds16(sh, lc + CST_SHIFT + c0);
-                if (defer) bottleneck_request(l - 1);
-                else if (a.has_hw && last_layer && !residual) bottleneck_request(l);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int p = pbase + 32 * m + n;
@@ -432,15 +448,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
                 load_first(pre_a, (gbf8p)(nb + (residual ? WP_RES_OFF : WP_CONV_OFF)) + q * 64 + lane);
             }
             if (!last_layer) cst_put(l + 1);
+            if (a.has_hw && last_layer && !residual) bottleneck_request(l);   // (the segment's last bottleneck: a stage of its own below)
             PFENCE();
             PSTAMP(sb + 2);
-            // ---- layer l-1's bottleneck, from the image this layer's GEMM has just read (no barrier of its own: the image stays
-            // intact until the barrier below)
-            if (defer) {
-                bottleneck_p<MT, NWAVE>(src, wb, bb, a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
-                if (a.has_hw && last_layer && !residual) bottleneck_request(l);   // (these four waves' registers were taken)
-            }
-            PSTAMP(sb + 7);
             __syncthreads();
             PFENCE();
             PSTAMP(sb + 3);
@@ -489,14 +499,13 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             if (last_layer) {
                 // ---- the segment's last layer has nobody to defer to: its bottleneck is a stage of its own, all eight waves (its
                 // weights were requested ahead of the barrier above).  First (a resumed segment) the next row's image is requested
-                // into the image that is now free: nothing the bottleneck waits for is behind it in the queue
-                // every load hipcc tracks is retired HERE (they were requested ahead of the barrier: no wait in practice), so that
+                // into the image that is now free: nothing the bottleneck waits for is behind it in the queue.
+                // Every load hipcc tracks is retired HERE (they were requested ahead of the barrier: no wait in practice), so that
                 // it places no vmcnt wait inside the stage that runs under the DMA -- one there would wait for the DMA as well
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (resumed && next_row >= 0) { dma_img = cur ^ 1; dma_read(next_row, dma_img, lane); }
                 if (a.has_hw)
-                    bottleneck_p<MT, NWAVE>(lds + cur * P_IMG_BYTES, wb, bb, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD,
-                                            L, wave, lane);
+                    bottleneck_ps<MT, NWAVE>(lds + cur * P_IMG_BYTES, wbq, bbq, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
             }
             PSTAMP(sb + 6);
         }

@@ -636,7 +636,134 @@ __global__ __launch_bounds__(256) void final_poolx_kernel(const bf8* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// FC on the bf16 matrix cores, split operands (dan_config.precision >= 1):  C = relu?(A W^T + bias), A fp32 [M][lda] (split into
+// hi / lo bf16 while it is staged), W as two bf16 planes [2][N][ldw] (split once at dan_finalize), three MFMAs per product
+// (ah wh + al wh + ah wl), fp32 sums -- the arithmetic of the conv stack's split kernel, ~2^-17 per operand.  With the fp32 MFMA
+// kernel (dan_kernels.hip::fc_kernel, 0.8 of ITS peak) FC1 was 4.4 ms per 4096 x 65 792 x 1024 macro-batch (7.1 ms at config 5's
+// 105 728 features) beside a conv stack on bf16 matrix cores.
+// The fp32 kernel's structure: 128 x 128 tiles, k-tiles of 32 staged through LDS (80-byte rows: conflict-free ds_read_b128),
+// double-buffered, XCD-contiguous tile order, the k range of a tile split over two co-resident workgroups (2 x 80 KiB of LDS)
+// whose partial sums fc_combine_kernel adds in a fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr int FX_BM = 128, FX_BN = 128, FX_BK = 32, FX_THREADS = 512;
+constexpr int FX_ROW = 80;                                   // bytes per LDS row: 32 bf16 + 16 bytes of padding
+constexpr int FX_PLANE = FX_BM * FX_ROW;                     // 10 240 B
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(FX_THREADS, 2) void fcx_kernel(const float* __restrict__ A, long long lda, const uint16_t* __restrict__ W,
+                                                            long long ldw, long long w_plane, const float* __restrict__ bias,
+                                                            float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
+                                                            int tiles_n, int n_tiles, int ksplit, float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) char lds[2][4 * FX_PLANE];   // per stage: A hi, A lo, W hi, W lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int n_work = n_tiles * ksplit;
+    const int per = (n_work + 7) >> 3;
+    const int qa = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || qa >= n_work) return;
+    const int q = qa / ksplit, part = qa - q * ksplit;
+    const int bm = (q / tiles_n) * FX_BM, bn = (q % tiles_n) * FX_BN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+    // staging: A: thread -> rows (tid >> 3) + 64 i, floats 4 (tid & 7) ..;  W: thread -> row tid >> 2, 8 bf16 at 8 (tid & 3), both planes
+    const int arow = tid >> 3, ac4 = (tid & 7) * 4, wrow = tid >> 2, wc8 = (tid & 3) * 8;
+    const float* ga[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ga[i] = A + (size_t)min(bm + arow + 64 * i, M - 1) * lda + ac4;
+    const uint16_t* gw = W + (size_t)min(bn + wrow, N - 1) * ldw + wc8;
+    v4f ra[2];
+    bf8 rwh, rwl;
+    auto gload = [&](int k0) {
+        const bool ina = k0 + ac4 < K, inw = k0 + wc8 < K;       // K is a multiple of 16: whole vectors
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = ina ? *(const v4f*)(ga[i] + k0) : (v4f){0.f, 0.f, 0.f, 0.f};
+        const bf8 z = {};
+        rwh = inw ? *(const bf8*)(gw + k0) : z;
+        rwl = inw ? *(const bf8*)(gw + w_plane + k0) : z;
+    };
+    auto sstore = [&](int buf) {
+        char* st = lds[buf];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)ra[i][j]; lo[j] = (__bf16)(ra[i][j] - (float)hi[j]); }
+            *(bf4*)(st + (arow + 64 * i) * FX_ROW + ac4 * 2) = hi;
+            *(bf4*)(st + FX_PLANE + (arow + 64 * i) * FX_ROW + ac4 * 2) = lo;
+        }
+        *(bf8*)(st + 2 * FX_PLANE + wrow * FX_ROW + wc8 * 2) = rwh;
+        *(bf8*)(st + 3 * FX_PLANE + wrow * FX_ROW + wc8 * 2) = rwl;
+    };
+    v4f acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const int KT_all = (K + FX_BK - 1) / FX_BK;
+    const int kts = (KT_all + ksplit - 1) / ksplit;
+    const int kt_lo = part * kts, KT = min(KT_all, kt_lo + kts);
+    gload(kt_lo * FX_BK);
+    sstore(kt_lo & 1);
+    __syncthreads();
+    for (int kt = kt_lo; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) gload((kt + 1) * FX_BK);
+        const char* st = lds[cur];
+        const unsigned oa = (unsigned)((wm + r16) * FX_ROW + kk * 16), ow = (unsigned)((wn + r16) * FX_ROW + kk * 16);
+        bf8 ah[4], al[4], wh[2], wl[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *(const bf8*)(st + oa + i * 16 * FX_ROW);
+            al[i] = *(const bf8*)(st + FX_PLANE + oa + i * 16 * FX_ROW);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wh[j] = *(const bf8*)(st + 2 * FX_PLANE + ow + j * 16 * FX_ROW);
+            wl[j] = *(const bf8*)(st + 3 * FX_PLANE + ow + j * 16 * FX_ROW);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = mfma16(ah[i], wh[j], acc[i][j]);
+                acc[i][j] = mfma16(al[i], wh[j], acc[i][j]);
+                acc[i][j] = mfma16(ah[i], wl[j], acc[i][j]);
+            }
+        if (kt + 1 < KT) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    float* wp = ksplit > 1 ? ws + (size_t)part * M * N : nullptr;  // raw partial sums; bias / ReLU in fc_combine_kernel
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn + j * 16 + r16;
+        if (n >= N) continue;
+        const float b = wp ? 0.f : bias[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = bm + wm + i * 16 + kk * 4 + jj;
+                if (m >= M) continue;
+                if (wp) { wp[(size_t)m * N + n] = acc[i][j][jj]; continue; }
+                float v = acc[i][j][jj] + b;
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)m * ldc + n] = v;
+            }
+    }
+}
+
 }  // namespace x3
+
+void launch_fcx(const float* A, long long lda, const uint16_t* W, long long ldw, long long w_plane, const float* bias, float* C,
+                long long ldc, int M, int N, int K, int relu, hipStream_t s, float* ws, long long ws_floats) {
+    const int tiles_m = (M + x3::FX_BM - 1) / x3::FX_BM, tiles_n = (N + x3::FX_BN - 1) / x3::FX_BN, n_tiles = tiles_m * tiles_n;
+    const int ksplit = (ws && ws_floats >= 2LL * M * N && K >= 64 * x3::FX_BK && n_tiles <= 384) ? 2 : 1;
+    const int grid = ((n_tiles * ksplit + 7) / 8) * 8;
+    hipLaunchKernelGGL(x3::fcx_kernel, dim3(grid), dim3(x3::FX_THREADS), 0, s, A, lda, W, ldw, w_plane, bias, C, ldc, M, N, K, relu, tiles_n,
+                       n_tiles, ksplit, ws);
+    if (ksplit > 1) launch_fc_combine(ws, ksplit, bias, C, ldc, M, N, relu, s);
+}
 
 void launch_read_meanx(const uint16_t* y, float* pool, int n_sites, int R, int L, const int* row_src, hipStream_t s) {
     const int n8 = L * (CPAD / 8);

@@ -26,10 +26,17 @@ mkdir -p "gpurun_out/prof_bf16_$tag"
 ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_bf16_$tag/kt" -- python3 "$root/bench.py" --precision 2 --reads 128 --window 301 --sites 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path > "$root/gpurun_out/prof_bf16_$tag/bench_under_rocprof.json" 2> "$root/gpurun_out/prof_bf16_$tag/kt.log" )
 timeout -k 10 400 tools/profile_pmc.sh "pmc_bf16_$tag" --precision 2 --reads 128 --window 301 --sites 2048 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path
 timeout -k 10 400 tools/profile_pmc.sh "pmc_train_$tag" --mode train --steps 2 --warmup 1 --no-cpu-baseline
+# ... and of the bf16x3 command (precision 1: dan_kernels_bf16x.hip)
+mkdir -p "gpurun_out/prof_bf16x3_$tag"
+( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_bf16x3_$tag/kt" -- python3 "$root/bench.py" --precision 1 --sites 16384 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path > "$root/gpurun_out/prof_bf16x3_$tag/bench_under_rocprof.json" 2> "$root/gpurun_out/prof_bf16x3_$tag/kt.log" )
+timeout -k 10 400 tools/profile_pmc.sh "pmc_bf16x3_$tag" --precision 1 --sites 4096 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path
 # stamped diagnostic build of the bf16 segment kernel and the GEMM-walk microbenchmarks (built here: binaries are not committed)
 hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/segp_probe.hip -o /tmp/segp_probe.bin 2> /dev/null
 timeout -k 10 60 /tmp/segp_probe.bin 0 2 301 > "$out/segp_probe_segment1.txt" 2>&1
 timeout -k 10 60 /tmp/segp_probe.bin 2 7 301 > "$out/segp_probe_segment2.txt" 2>&1
+hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/segx_probe.hip -o /tmp/segx_probe.bin 2> /dev/null
+timeout -k 10 60 /tmp/segx_probe.bin 0 2 201 64 > "$out/segx_probe_segment1.txt" 2>&1
+timeout -k 10 60 /tmp/segx_probe.bin 2 7 201 64 > "$out/segx_probe_segment2.txt" 2>&1
 hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_bf16_feed.hip -o /tmp/mfma_bf16_feed.bin 2> /dev/null
 hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_alone.hip -o /tmp/gemm_p_alone.bin 2> /dev/null
 hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_lone.hip -o /tmp/gemm_p_lone.bin 2> /dev/null

@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
         const bool res = (a.res_mask >> l) & 1;
         printf("L%d  pre %6lld | conv %7lld w0 %7lld w7 %7lld | epi %6lld | deferred bottleneck w0 %6lld w7 %6lld | barrier wait w0 %6lld w7 %6lld | res gemm(+seed) %7lld | res write+bar %6lld | own bottleneck %6lld\n",
                l + 1, med(l == l_begin ? 1 : sb - 2, sb, -1), med(sb, sb + 1, -1), med(sb, sb + 1, 0), med(sb, sb + 1, 7),
-               med(sb + 1, sb + 2, -1), med(sb + 2, sb + 7, 0), med(sb + 2, sb + 7, 7), med(sb + 7, sb + 3, 0), med(sb + 7, sb + 3, 7),
+               med(sb + 7, sb + 2, -1), med(sb + 1, sb + 7, 0), med(sb + 1, sb + 7, 7), med(sb + 2, sb + 3, 0), med(sb + 2, sb + 3, 7),
                res ? med(sb + 3, sb + 4, -1) : 0LL, res ? med(sb + 4, sb + 5, -1) : 0LL,
                med(res ? sb + 5 : sb + 3, sb + 6, -1));
     }

@@ -137,14 +137,16 @@ def extras(tag, dst):
     tpath = os.path.join(dst, tag + "_traffic.json")
     traffic = json.load(open(tpath))
     for name, what, cmd in (("train", "bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline   (tools/profile_train.sh)", None),
-                            ("bf16", "bench.py --precision 2 --reads 128 --window 301 --sites 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path", None)):
+                            ("bf16", "bench.py --precision 2 --reads 128 --window 301 --sites 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path", None),
+                            ("bf16x3", "bench.py --precision 1 --sites 16384 --steps 2 --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path", None)):
         hits = sorted(glob.glob(os.path.join(go, "prof_%s_%s" % (name, tag), "kt", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         if hits:
             with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as out:
                 out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 %s   (kernel_stats.csv, verbatim)\n" % what)
                 out.write(open(hits[-1]).read())
     pmc = {"train": ("--mode train --steps 2 --warmup 1 --no-cpu-baseline", 3),
-           "bf16": ("--precision 2 --reads 128 --window 301 --sites 2048 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path", 1)}
+           "bf16": ("--precision 2 --reads 128 --window 301 --sites 2048 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path", 1),
+           "bf16x3": ("--precision 1 --sites 4096 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path", 1)}
     for name, (command, passes) in pmc.items():
         src = os.path.join(go, "pmc_%s_%s" % (name, tag))
         if not os.path.isdir(src):
@@ -157,6 +159,12 @@ def extras(tag, dst):
             traffic["train_step"] = {"command": "bench.py " + command, "hbm_bytes_per_step": total,
                                      "note": "sum over every kernel of the step of (2 x FETCH_SIZE + WRITE_SIZE) per dispatch x dispatches, "
                                              "/ %d steps; 64 sites x 100 reads x 201 bp" % passes}
+        elif name == "bf16x3":
+            for r in rows:
+                if "segmentx_kernel" in r["kernel"]:
+                    traffic["segmentx_kernel_bytes_per_launch"] = {
+                        "command": "bench.py " + command, "total": float(r["hbm_bytes"]), "dispatches": int(r["dispatches"]),
+                        "note": "chunk of 2048 sites x 64 reads x 201 bp, averaged over the two launches of a chunk (layers 1-2, layers 3-7)"}
         else:
             for r in rows:
                 if "segmentp_kernel" in r["kernel"]:
@@ -172,6 +180,8 @@ def extras(tag, dst):
             base = os.path.basename(f)[:-5]
             if base == "train" and "train_step" in traffic:
                 rec["roofline"]["traffic"] = int(traffic["train_step"]["hbm_bytes_per_step"])
+            if base == "bf16x3" and "segmentx_kernel_bytes_per_launch" in traffic:
+                rec["roofline"]["traffic"] = int(traffic["segmentx_kernel_bytes_per_launch"]["total"])
             if base == "bf16_128x301" and "segmentp_kernel_bytes_per_launch" in traffic:
                 rec["roofline"]["traffic"] = int(traffic["segmentp_kernel_bytes_per_launch"]["total"])
             with open(os.path.join(dst, "%s_bench_line_%s.json" % (tag, base)), "w") as out:
