@@ -326,7 +326,9 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         // outputs h stay under 48 GB -- 288 GB of HBM per GPU: fewer, larger launches (2048 sites at 64 x 201: +1.7 % over 128) --
         // and under a third of what the device has FREE now (a shared or smaller device sizes down instead of failing in hipMalloc;
         // the feature matrix, FC workspaces and weights take their share of the rest)
-        const double per_site = (double)c.reads * c.length * (CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * sizeof(float);
+        // (precision 2 keeps y and h as bf16: half the bytes per site, twice the sites per chunk -- 1024 at 128 x 301)
+        const double elem = c.precision == 2 ? 2.0 : 4.0;
+        const double per_site = (double)c.reads * c.length * (CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * elem;
         double budget = 48e9;
         size_t free_b = 0, total_b = 0;
         if (hipSetDevice(c.device_id) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
@@ -583,7 +585,8 @@ int dan_finalize(dan_t* h) {
 
     // ---- activations / workspaces, sized for one chunk (conv) and one macro-batch (FC)
     const size_t read_floats = (size_t)L * CPAD;
-    if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats))) return rc;
+    const size_t act_div = h->use_p ? 2 : 1;                 // (bf16 y / h: half a float per element)
+    if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats / act_div))) return rc;
     if ((rc = dev_alloc(h, &h->d_pool, (size_t)h->chunk * read_floats))) return rc;
     if (conv_pool && h->n_segments > 1) {
         if ((rc = dev_alloc(h, &h->d_cp, (size_t)h->chunk * read_floats))) return rc;
@@ -597,7 +600,7 @@ int dan_finalize(dan_t* h) {
         h->d_work = (int*)tmp;
         h->d_work_count = h->d_work + (size_t)h->chunk * R;
     }
-    if (H > 0 && (rc = dev_alloc(h, &h->d_h, (size_t)c.layers * h->chunk * R * L * HPAD))) return rc;
+    if (H > 0 && (rc = dev_alloc(h, &h->d_h, (size_t)c.layers * h->chunk * R * L * HPAD / act_div))) return rc;
     if ((rc = dev_alloc(h, &h->d_feat, (size_t)h->max_batch * h->F_stride))) return rc;
     HIPCHK(h, hipMemset(h->d_feat, 0, (size_t)h->max_batch * h->F_stride * sizeof(float)));
     if ((rc = dev_alloc(h, &h->d_hid0, (size_t)h->max_batch * h->n0_stride)) || (rc = dev_alloc(h, &h->d_hid1, (size_t)h->max_batch * n1))) return rc;
