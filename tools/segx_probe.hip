@@ -7,6 +7,9 @@
 #include <vector>
 #include <algorithm>
 using namespace dan;
+namespace dan {   // (launch_fcx's combine step lives in dan_kernels.hip; the probe never calls it)
+void launch_fc_combine(const float*, int, const float*, float*, long long, int, int, int, hipStream_t) {}
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
