@@ -46,7 +46,8 @@ struct RowArgs {
     const float* bias2;                     // [HPAD]
     float* out2;                            // rows (HPAD stride)
 };
-// returns the number of `stats` entries written ([entry][2][CPAD]): reads, or 64-position tiles for the pointwise (1x1) launches
+// returns the number of `stats` entries written ([entry][2][CPAD]): reads (the whole-read kernel), half-read units (the 3-tap
+// launches of the direct form: train_rowh_kernel), or 64-position tiles (the pointwise 1x1 launches)
 int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s);
 
 // ---- T2: weight gradient  dW[t][o][c] = sum over positions of  A[p][o] * B[p + (t - 1) dil][c]   (+ bias grad = sum A) ------

@@ -6,7 +6,7 @@
 // embedding gradient rules model.py:143-145 (padding_idx, scale_grad_by_freq).
 //
 // Layout and schedule: see dan_train.h.  One workgroup (8 waves) = one read resident in LDS for ONE layer-shaped step
-// (train_row_kernel): the convolution, its transpose (data gradient), the 1x1 residual and bottleneck GEMMs and their
+// (train_row_kernel; the 3-tap launches of the direct form run on half reads, two workgroups per CU: train_rowh_kernel): the convolution, its transpose (data gradient), the 1x1 residual and bottleneck GEMMs and their
 // transposes are all the same implicit GEMM over the LDS image (conv_gemm of dan_device.h) with weights re-packed on the
 // device every step.  Weight gradients contract over positions (train_wgrad_kernel): persistent workgroups, both operands
 // staged per half read, split-K partials reduced in a fixed order.  Every reduction is deterministic (no atomics).
@@ -302,6 +302,127 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// T1h: the 3-tap launches of the direct form (forward convolution, data gradient) on HALF reads, two workgroups per CU.
+// A whole-read workgroup owns its CU alone (the image is 118 KB), so its memory phases -- 100-200 KB of rows in, 100 KB out, at
+// a CU's 20 GB/s share of HBM -- and its GEMM take turns: every CU loads, then every CU multiplies, HBM idle under the GEMMs and
+// the matrix pipes idle under the copies (1.25 ms per launch where the MFMAs alone are 0.87 ms and the rows 0.35 ms).  One layer
+// per launch needs no whole read: a unit here is 7 (or 6) position tiles of a read plus 4 halo rows either side, 64 KB of LDS,
+// four waves (wave = 32 output channels x the unit's tiles: the same wave tile as above), and the two workgroups of a CU run
+// half a unit apart (the second one sleeps first), one's rows travelling under the other's GEMM.  No prefetch registers, no
+// second GEMM stage, no addends: what the two 3-tap launch kinds need and nothing else.  stats entries are per unit.
+// tools/rowh_probe.hip, 6400 reads: whole read 1.235 / 1.21 ms (forward / data gradient), half reads 1.10 / 1.14 ms, of which
+// 1.03 ms remain with the loads and stores switched off (LDS staging, barriers, GEMM, epilogue arithmetic: the GEMM core's own
+// 0.84 of the MFMA rate); one workgroup per CU 1.29 ms; the start offset is worth 4 % on the forward launches, nothing on the
+// data gradient (upper half of the grid or odd workgroups, one to five sleeps: all within 1 %).
+// ------------------------------------------------------------------------------------------------
+constexpr int RH_THREADS = 256, RH_ROWS = MTW * 16 + 2 * HALO;                    // 120 image rows
+__global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, int n_rows, int stagger) {
+    __shared__ __attribute__((aligned(16))) float xs[RH_ROWS * LDS_S];
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);                    // = the channel quarter
+    const int L = a.L;
+    const int n_units = 2 * n_rows;
+    if ((stagger & 255) && ((stagger & 256) ? (blockIdx.x & 1) : ((int)blockIdx.x >= (int)gridDim.x / 2))) {
+        for (int i = 0; i < (stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    int k_it = 0;
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x, ++k_it) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                           // (per-lane addresses are formed per unit, not kept across the GEMM)
+        const int lane = tid & 63;
+        const int row = u >> 1, half = (u ^ k_it) & 1;          // a workgroup alternates between the 7-tile and the 6-tile half
+        const int site = row / a.R;
+        const int p0 = half * (MTW * 16), cnt = half ? MT - MTW : MTW;
+        // ---- the image: rows [p0 - HALO, p0 + 112 + HALO) of the read, zero outside the window
+        if (a.mode == 0) {
+            for (int i = tid; i < RH_ROWS * LDS_S / 4; i += RH_THREADS) ((v4f*)xs)[i] = splat(0.f);
+            __syncthreads();
+            EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
+            encode_rows(xs, LDS_S, 0, p0 - HALO, p0 - HALO + RH_ROWS, e, (size_t)row, site, L, tid);
+        } else {
+            constexpr int NP = RH_ROWS * (CPAD / 4) / RH_THREADS;                   // 15
+            static_assert(NP * RH_THREADS == RH_ROWS * (CPAD / 4), "the staging covers the image exactly");
+            const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * CPAD);
+            const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)row * L * CPAD) : nullptr;
+            const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
+            v4f r1[NP], r2[NP], r3[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * RH_THREADS;
+                const int p = p0 - HALO + (i >> 5);
+                const bool ok = p >= 0 && p < L;
+                const int g = p * (CPAD / 4) + (i & 31);
+                r1[k] = ok ? s1[g] : splat(0.f);
+                r2[k] = (ok && s2) ? s2[g] : splat(0.f);
+                r3[k] = (ok && pl) ? pl[g] : splat(0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * RH_THREADS;
+                const int pr = i >> 5, c4 = i & 31, p = p0 - HALO + pr;
+                const bool ok = p >= 0 && p < L;
+                *(v4f*)(xs + pr * LDS_S + c4 * 4) = ok ? load_transform(r1[k], r2[k], a.coef, c4 * 4, a.mask_src2) + r3[k] : splat(0.f);
+            }
+        }
+        __syncthreads();
+        const int pos = lane & 15, kk = lane >> 4;
+        int chb[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) chb[n] = (wave * NT + n) * 16 + kk * 4;
+        v4f acc[MTW][NT];
+        {
+            gv4f_ptr w = (gv4f_ptr)(a.w1) + (wave * NT) * 64 + lane;
+            const v4f first[NT] = {w[0], w[64]};
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = splat(0.f);
+            conv_gemm(acc, xs, w, first, a.kg, a.taps, a.dil, lane, 0, cnt);
+        }
+        // ---- epilogue: out1 = [relu](acc + bias1); stats[u] = (sum out1, sum out1^2) over the unit's positions
+        const size_t rbase = (size_t)row * L * CPAD;
+        v4f s0[NT], s1v[NT], bias[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            s0[n] = splat(0.f); s1v[n] = splat(0.f);
+            bias[n] = a.bias1 ? *(const v4f*)(a.bias1 + chb[n]) : splat(0.f);
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int p = p0 + m * 16 + pos;
+            if (m < cnt && p < L) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    v4f v = acc[m][n] + bias[n];
+                    if (a.relu_out) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    s0[n] += v;
+                    s1v[n] += v * v;
+                    *(v4f*)(a.out1 + rbase + (size_t)p * CPAD + chb[n]) = v;
+                }
+            }
+        }
+        if (a.stats) {                                           // every channel belongs to exactly one (wave, tile, k-quarter, j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = s0[n][j], y = s1v[n][j];
+#pragma unroll
+                    for (int msk = 1; msk < 16; msk <<= 1) { x += __shfl_xor(x, msk); y += __shfl_xor(y, msk); }
+                    if (pos == 0) {
+                        a.stats[((size_t)u * 2 + 0) * CPAD + chb[n] + j] = x;
+                        a.stats[((size_t)u * 2 + 1) * CPAD + chb[n] + j] = y;
+                    }
+                }
+        }
+        __syncthreads();                                         // every wave has finished reading the image
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // T1p: the POINTWISE launches (1x1 GEMMs: BN-apply [+ residual] + bottleneck, the accumulation of g_l with the bottleneck's
 // transpose, the residual's transpose).  Nothing reaches sideways, so the unit is a tile of 64 positions of the flat
 // [rows * L] position axis instead of a whole read: 35 KB of LDS and <= 128 registers, FOUR workgroups (16 waves) per CU, and
@@ -521,6 +642,19 @@ int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
         const int tiles = (int)((n_pos + TP_POS - 1) / TP_POS);
         hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
         return tiles;
+    }
+    static const int n_cus_h = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.add2 && !a.addb && !a.stat_aux &&
+                            (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS;
+    if (half_units) {
+        const int n_units = 2 * n_rows, wgs = std::min(n_units, 2 * n_cus_h);
+        // the second workgroup of a CU starts half a unit late (three s_sleep 127: ~10 us) when there is a second one per CU
+        hipLaunchKernelGGL(train_rowh_kernel, dim3((unsigned)wgs), dim3(RH_THREADS), 0, s, a, n_rows, wgs > n_cus_h ? 3 : 0);
+        return n_units;
     }
     static const int n_cus = [] {
         int dev = 0, n = 0;

@@ -115,12 +115,48 @@ def test_train_forward_activations_match_oracle():
     tr.close()
 
 
+def decisions_differing(tr, w64, cfg, B):
+    """The discrete decisions of the HIP step just run on ``tr`` that differ from the float64 oracle's (``w64``: its result with
+    taps): [(where, count, largest |oracle operand| among them)] for the conv / bottleneck ReLU masks and the read that wins the
+    final max (exact ties -- reads with identical receptive fields -- are not decisions: whichever takes the gradient, every
+    parameter gradient is the same)."""
+    R, L = cfg.reads, cfg.length
+    out = []
+
+    def rows(name, width, C):                                       # [B][R][L][width] device layout -> (B, C, R, L)
+        return np.transpose(tr.debug_buffer(name, B * R * L * width).reshape(B, R, L, width)[..., :C], (0, 3, 1, 2))
+
+    for l in range(1, cfg.layers + 1):
+        pre = w64["tap:pre%d" % l]
+        d = (rows("act:a%d" % l, 128, pre.shape[1]) > 0) != (pre > 0)
+        out.append(("conv", l, int(d.sum()), float(np.abs(pre[d]).max()) if d.any() else 0.0))
+        if cfg.bottleneck > 0:
+            hpre = w64["tap:hpre%d" % l]
+            d = (rows("act:h%d" % l, 32, hpre.shape[1]) > 0) != (hpre > 0)
+            out.append(("bott", l, int(d.sum()), float(np.abs(hpre[d]).max()) if d.any() else 0.0))
+    xo = w64["tap:conv%d" % cfg.layers]
+    xl = rows("act:x%d" % cfg.layers, 128, xo.shape[1])
+    am, ao = xl.argmax(axis=2), xo.argmax(axis=2)
+    gap = np.take_along_axis(xo, ao[:, :, None, :], 2)[:, :, 0, :] - np.take_along_axis(xo, am[:, :, None, :], 2)[:, :, 0, :]
+    real = (am != ao) & (gap > 0)
+    out.append(("max", cfg.layers, int(real.sum()), float(gap[real].max()) if real.any() else 0.0))
+    return out
+
+
 def test_production_width_step_against_oracle():
-    """Full-width network (7 x 128 channels, bottleneck 32, all MFMA tiles live) on a small batch: every gradient against the
-    training oracle (which tests/test_train_oracle.py pins to the reference's loop) evaluated in FLOAT64.  At this width
-    fp32 itself is the limit: the fp32 oracle sits up to 2e-3 (of a tensor's max) from the float64 one on the smallest
-    gradients (a ReLU / max-pool decision flipping on a rounding error), so each tensor is allowed 1e-4 plus twice the fp32
-    oracle's own distance from float64 -- an fp32 implementation cannot be asked for more."""
+    """Full-width network (7 x 128 channels, bottleneck 32, all MFMA tiles live) on a small batch of UNMODIFIED synthetic
+    pileups: every gradient against the training oracle (which tests/test_train_oracle.py pins to the reference's loop)
+    evaluated in FLOAT64.  At this width fp32 itself is the limit: a ReLU input or a top-1 / top-2 gap of the final max that
+    lies within an fp32 rounding error of its edge is decided the other way by some fp32 evaluations, and ONE such decision
+    moves gradient tensors by up to 2e-2 of their max (tests/diagnostics/prod_width_seeds.py: over eight seeds the fp32 torch
+    oracle sits 1e-6 .. 2e-3 from the float64 one, this step 2e-6 .. 2e-2, three of the eight with a single flipped max).
+    So the test is in two parts:
+      * every decision of the HIP step that differs from the float64 oracle's must sit on a rounding edge (operand within
+        DECISION_MARGIN of it) -- a decision that differs on a large value is a bug;
+      * if NO decision differs, every tensor is within 1e-4 of its max plus twice the fp32 oracle's own distance from float64;
+        otherwise (the step computed the gradient of a network one rounding error away) within a loose 5e-2.
+    test_production_width_step_strict_bar_when_no_decision_sits_on_a_rounding_error below moves every decision off its edge and
+    holds the same network to the strict bar unconditionally."""
     cfg = DanConfig(reads=12, fc_sizes=(64, 32))
     sd = random_state_dict(cfg, seed=17)
     for k in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
@@ -137,17 +173,26 @@ def test_production_width_step_against_oracle():
     masks = [(rng.random((B, w)) >= hp.dropout).astype(np.uint8) for w in widths]
     ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
     import torch
-    want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64)
+    want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64, taps=True)
     w32 = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks)
     tr = DanTrainer(cfg, hp, max_batch=8).load_state_dict(sd)
     out = tr.train_step(batch.arrays(), tg, dropout_masks=masks)
     for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr"):
         assert abs(out[k] - float(want[k])) <= 5e-5 * max(1.0, abs(float(want[k]))), (k, out[k], float(want[k]))
-    assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * float(want["grad_norm"])
+    differing = [d for d in decisions_differing(tr, want, cfg, B) if d[2]]
+    for kind, l, n, largest in differing:
+        assert largest <= DECISION_MARGIN[kind], "%d %s decisions of layer %d differ from the float64 oracle's, one on an operand of %.3g" % (n, kind, l, largest)
     grads = {k[5:]: v for k, v in want.items() if k.startswith("grad:")}
-    slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
-    worst = check_grads(tr, grads, "production width", slack)
-    print("production width: worst gradient %s at %.2g of its max" % worst)
+    if not differing:
+        assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * float(want["grad_norm"])
+        slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
+        worst = check_grads(tr, grads, "production width", slack)
+    else:
+        worst = check_grads(tr, grads, "production width, %d decisions on rounding edges" % sum(d[2] for d in differing),
+                            {k: 0.5 * (5e-2 - GRAD_RTOL) for k in grads})
+    print("production width: %s; worst gradient %s at %.2g of its max" % (
+        "no decision differs from the float64 oracle's" if not differing else
+        "decisions on rounding edges that went the other way: " + ", ".join("%s %d: %d (operand <= %.1e)" % d for d in differing), *worst))
     tr.close()
 
 
