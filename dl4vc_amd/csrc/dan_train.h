@@ -38,6 +38,8 @@ struct RowArgs {
     const float* bias1;                     // [CPAD] or nullptr
     int relu_out;
     const float *add1, *add2;               // row addends (CPAD stride) or nullptr
+    const float* add1_coef;                 // [3][CPAD]: the first addend enters as A[c] * add1 + C[c] (a BatchNorm output that was
+                                            //    never written: pointwise launches only), or nullptr
     const float* addb;                      // per-site addend [site][L][CPAD] or nullptr
     float* out1;                            // rows (CPAD stride) or nullptr
     float* stats;                           // [row][2][CPAD] or nullptr

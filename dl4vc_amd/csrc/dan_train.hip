@@ -58,6 +58,26 @@ __device__ __forceinline__ void encode_rows(float* img, int stride, int row_off,
     }
 }
 
+// The same with the three constants of the thread's channels already in registers.  Every staging loop below walks positions
+// with a stride that is a multiple of the row's vector count, so a thread meets the SAME four channels in every iteration:
+// fetched per element (three 16-byte loads beside every 16-byte row load) the constants cost the half-read conv launch 60 us
+// of its 1.1 ms.
+struct Coef3 { v4f A, B, C; };
+__device__ __forceinline__ Coef3 load_coef(const float* coef, int c) {
+    Coef3 k{splat(1.f), splat(0.f), splat(0.f)};
+    if (coef) { k.A = *(const v4f*)(coef + c); k.B = *(const v4f*)(coef + CPAD + c); k.C = *(const v4f*)(coef + 2 * CPAD + c); }
+    return k;
+}
+__device__ __forceinline__ v4f apply_transform(v4f s1, v4f s2, const Coef3& k, bool has_coef, int mask) {
+    v4f v = s1;
+    if (has_coef) v = k.A * s1 + k.B * s2 + k.C;
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = s2[j] > 0.f ? v[j] : 0.f;
+    }
+    return v;
+}
+
 // v = A s1 + B s2 + C, then masked by s2 > 0
 __device__ __forceinline__ v4f load_transform(v4f s1, v4f s2, const float* coef, int c, int mask) {
     v4f v = s1;
@@ -345,6 +365,7 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
             const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * CPAD);
             const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)row * L * CPAD) : nullptr;
             const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
+            const Coef3 ck = load_coef(a.coef, (tid & 31) * 4);     // (i & 31 == tid & 31 in every iteration below)
             v4f r1[NP], r2[NP], r3[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
                 const int i = tid + k * RH_THREADS;
                 const int pr = i >> 5, c4 = i & 31, p = p0 - HALO + pr;
                 const bool ok = p >= 0 && p < L;
-                *(v4f*)(xs + pr * LDS_S + c4 * 4) = ok ? load_transform(r1[k], r2[k], a.coef, c4 * 4, a.mask_src2) + r3[k] : splat(0.f);
+                *(v4f*)(xs + pr * LDS_S + c4 * 4) = ok ? apply_transform(r1[k], r2[k], ck, a.coef != nullptr, a.mask_src2) + r3[k] : splat(0.f);
             }
         }
         __syncthreads();
@@ -444,6 +465,7 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
         const v4f* s1 = (const v4f*)a.src1 + base * vpr;
         const v4f* s2 = a.src2 ? (const v4f*)a.src2 + base * vpr : nullptr;
         constexpr int NP = TP_POS * (CPAD / 4) / TP_THREADS;        // 8
+        const Coef3 ck = load_coef(a.coef, (tid & (vpr - 1)) * 4);  // vpr is 32 or 8: i mod vpr == tid mod vpr in every iteration
         v4f r1[NP], r2[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -457,7 +479,7 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
             const int i = tid + k * TP_THREADS;
             if (i < TP_POS * vpr) {
                 const int pr = i / vpr, c4 = i - pr * vpr;
-                *(v4f*)(xs + pr * LDS_S + c4 * 4) = (pr < n_here) ? load_transform(r1[k], r2[k], a.coef, c4 * 4, a.mask_src2) : splat(0.f);
+                *(v4f*)(xs + pr * LDS_S + c4 * 4) = (pr < n_here) ? apply_transform(r1[k], r2[k], ck, a.coef != nullptr, a.mask_src2) : splat(0.f);
             }
         }
         if (vpr < CPAD / 4) {                                    // 32-channel input: the GEMM reads only its kg groups, nothing to clear
@@ -528,6 +550,14 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
     if (a.add1) {
         v4f t[TP_MT][NT];
         fetch(a.add1, t);
+        if (a.add1_coef) {                                       // the addend is a BatchNorm output that exists only as its input
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const v4f A = *(const v4f*)(a.add1_coef + chb[n]), C = *(const v4f*)(a.add1_coef + 2 * CPAD + chb[n]);
+#pragma unroll
+                for (int m = 0; m < TP_MT; ++m) t[m][n] = (m * 16 + pos < n_here) ? A * t[m][n] + C : splat(0.f);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < TP_MT; ++m)
 #pragma unroll
@@ -705,6 +735,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                 const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * a.a_stride);
                 const v4f* s2 = a.a2 ? (const v4f*)(a.a2 + (size_t)row * L * a.a_stride) : nullptr;
                 constexpr int NIT = (WG_CH * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;       // 7 at 128 channels
+                const Coef3 ck = load_coef(a.a_coef, (tid & (vpa - 1)) * 4);                    // vpa is 32 or 8: i mod vpa == tid mod vpa
                 v4f r1[NIT], r2[NIT];
 #pragma unroll
                 for (int k = 0; k < NIT; ++k) {
@@ -720,7 +751,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                     const int i = tid + k * SEG_THREADS;
                     if (i < WG_CH * vpa) {
                         const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
-                        const v4f v = (p < L) ? load_transform(r1[k], r2[k], a.a_coef, c4 * 4, a.a_mask) : splat(0.f);
+                        const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
                         *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
                         bsum += v;
                     }
@@ -737,6 +768,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                 const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
                 constexpr int NIT = BROWS * (CPAD / 4) / SEG_THREADS;                            // 7
                 static_assert(NIT * SEG_THREADS == BROWS * (CPAD / 4), "B staging covers the image exactly");
+                const Coef3 cb = load_coef(a.b_coef, (tid & 31) * 4);
                 v4f r1[NIT], r2[NIT];
 #pragma unroll
                 for (int k = 0; k < NIT; ++k) {
@@ -752,7 +784,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                     const int i = tid + k * SEG_THREADS;
                     const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
                     v4f v = r1[k];
-                    if (a.b_coef && p >= 0 && p < L) v = *(const v4f*)(a.b_coef + c4 * 4) * v + *(const v4f*)(a.b_coef + 2 * CPAD + c4 * 4);
+                    if (a.b_coef && p >= 0 && p < L) v = cb.A * v + cb.C;
                     *(v4f*)(sb + pl * WG_S + c4 * 4) = v + r2[k];
                 }
             }

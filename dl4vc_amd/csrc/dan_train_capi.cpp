@@ -71,6 +71,8 @@ struct dan_trainer {
     std::vector<float*> pk_conv_f, pk_conv_d, pk_res_f, pk_res_d, pk_bot_f, pk_bot_d;
     std::vector<float*> pk_wino_f, pk_wino_d;                 // Winograd F(2,3) forms of the conv / its data gradient (dilation-2 layers)
     std::vector<int> wino_layer;
+    std::vector<int> lazy_x;                 // [l] 1: x_l = bn(a_l) is never written -- its consumers form it from a_l as they load
+    float* d_xtap = nullptr;                 // scratch for the "act:x<l>" debug tap of such a layer
     float* d_wino_u = nullptr;                                // [128][128][4] scratch of the weight transform
     float *d_wc_pk = nullptr, *d_wct = nullptr, *d_bc_pad = nullptr;
     float* d_bias = nullptr;                                  // [layers][3][CPAD]: conv bias, residual bias, bottleneck bias (padded)
@@ -364,8 +366,18 @@ int dan_train_finalize(dan_trainer_t* t) {
     // ---- activations
     const size_t rowf = (size_t)L * CPAD;
     t->d_a.resize(NL); t->d_x.resize(NL); t->d_pool.assign(NL + 1, nullptr);
+    // A BatchNorm output x_l that feeds nothing but the next layer's convolution and its own highway branch is never written: the
+    // pointwise launch behind layer l still forms it (for h_l) but stores only h_l, and its three consumers -- the next conv
+    // launch, that layer's weight gradient, the bottleneck's weight gradient -- form it again from a_l with the same three
+    // per-channel constants as they stage their operands (one multiply-add per element they load anyway): 658 MB less HBM write
+    // per layer at 64 sites.  Not for a residual layer (x_l comes out of a 1x1 GEMM), a pooled one (the read mean reads x_l)
+    // or the last one (the final pools read it).
+    t->lazy_x.assign(NL, 0);
+    for (int l = 0; l + 1 < NL; ++l) t->lazy_x[l] = !t->layers[l].residual && !pool_after(c, l + 1) && H > 0;
     for (int l = 0; l < NL; ++l) {
-        if ((rc = talloc(t, &t->d_a[l], rows * rowf, false)) || (rc = talloc(t, &t->d_x[l], rows * rowf, false))) return rc;
+        if ((rc = talloc(t, &t->d_a[l], rows * rowf, false))) return rc;
+        t->d_x[l] = nullptr;
+        if (!t->lazy_x[l] && (rc = talloc(t, &t->d_x[l], rows * rowf, false))) return rc;
         if (pool_after(c, l + 1) && (rc = talloc(t, &t->d_pool[l + 1], (size_t)B * rowf, false))) return rc;
     }
     if (H > 0 && ((rc = talloc(t, &t->d_h, (size_t)NL * rows * L * HPAD, false)) || (rc = talloc(t, &t->d_dh, (size_t)NL * rows * L * HPAD, false)))) return rc;
@@ -521,6 +533,7 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             RowArgs a{};
             a.R = R; a.L = L;
             if (l == 0) { a.mode = 0; fill_encode(a, t, B); }
+            else if (t->lazy_x[l - 1]) { a.mode = 1; a.src1 = t->d_a[l - 1]; a.s1_stride = CPAD; a.coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
             else { a.mode = 1; a.src1 = t->d_x[l - 1]; a.s1_stride = CPAD; a.pool_in = t->d_pool[l]; }
             a.w1 = t->pk_conv_f[l]; a.taps = 3; a.kg = lp.kg; a.dil = lp.dil;
             if (t->wino_layer[l]) { a.w1 = t->pk_wino_f[l]; a.wino = 1; }
@@ -538,7 +551,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             RowArgs a{};
             a.R = R; a.L = L; a.mode = 1; a.src1 = t->d_a[l]; a.s1_stride = CPAD; a.coef = coef_f;
             if (lp.residual) { a.w1 = t->pk_res_f[l]; a.taps = 1; a.kg = KGC; a.dil = 0; a.bias1 = bias + CPAD; a.add1 = t->d_x[l - 1]; }
-            a.out1 = t->d_x[l];
+            if (lp.residual && t->lazy_x[l - 1]) { a.add1 = t->d_a[l - 1]; a.add1_coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
+            a.out1 = t->d_x[l];                              // (nullptr for a lazy layer: the launch then only writes h_l)
             if (H > 0) { a.w2 = t->pk_bot_f[l]; a.bias2 = bias + 2 * CPAD; a.out2 = t->d_h + (size_t)l * n_rows * L * HPAD; }
             launch_train_row(a, n_rows, s);
         }
@@ -653,6 +667,7 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             WgradArgs w{};
             w.R = R; w.L = L; w.n_rows = n_rows; w.a1 = t->d_dh + (size_t)l * h_layer; w.a_stride = HPAD; w.a2 = t->d_h + (size_t)l * h_layer; w.a_mask = 1;
             w.b_mode = 1; w.b1 = t->d_x[l];
+            if (t->lazy_x[l]) { w.b1 = t->d_a[l]; w.b_coef = t->d_coef_f + (size_t)l * 3 * CPAD; }
             w.taps = 1; w.dil = 0; w.o_tiles = 2; w.c_tiles = KGC; w.partial = t->d_partial; w.bias_partial = t->d_bias_partial;
             const int wgs = launch_train_wgrad(w, s);
             launch_wgrad_reduce(t->d_partial, t->d_bias_partial, wgs, 1, 2 * 16, CPAD, H, lp.cout, nullptr, gp(t, lp.bot_w), gp(t, lp.bot_b), s);
@@ -667,6 +682,7 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
                 w.emb = e.emb; w.pe = e.pe;
             } else {
                 w.b_mode = 1; w.b1 = t->d_x[l - 1]; w.b_pool = t->d_pool[l];
+                if (t->lazy_x[l - 1]) { w.b1 = t->d_a[l - 1]; w.b_coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
             }
             w.taps = 3; w.dil = lp.dil; w.o_tiles = KGC; w.c_tiles = (l == 0) ? KG0 : KGC; w.partial = t->d_partial; w.bias_partial = t->d_bias_partial;
             const int wgs = launch_train_wgrad(w, s);
@@ -825,7 +841,16 @@ int64_t dan_train_get_tensor(dan_trainer_t* t, const char* name, float* dst, int
         const int l = atoi(nm.c_str() + 5) - 1;
         if (l < 0 || l >= c.layers) return failt(t, DAN_ERR_INVALID_ARG, "'%s': no such layer", name);
         if (nm[4] == 'a') { src = t->d_a[l]; n = rows * c.length * CPAD; }
-        else if (nm[4] == 'x') { src = t->d_x[l]; n = rows * c.length * CPAD; }
+        else if (nm[4] == 'x' && t->lazy_x[l]) {              // a layer whose x is never written: formed here for the tap
+            int rc0 = 0;
+            if (!t->d_xtap && (rc0 = talloc(t, &t->d_xtap, (size_t)t->max_batch * c.reads * c.length * CPAD, false))) return rc0;
+            RowArgs a{};
+            a.R = c.reads; a.L = c.length; a.mode = 1; a.src1 = t->d_a[l]; a.s1_stride = CPAD; a.coef = t->d_coef_f + (size_t)l * 3 * CPAD;
+            a.out1 = t->d_xtap;
+            launch_train_row(a, (int)rows, nullptr);
+            HIPT(t, hipDeviceSynchronize());
+            src = t->d_xtap; n = rows * c.length * CPAD;
+        } else if (nm[4] == 'x') { src = t->d_x[l]; n = rows * c.length * CPAD; }
         else if (nm[4] == 'h' && t->d_h) { src = t->d_h + (size_t)l * rows * c.length * HPAD; n = rows * c.length * HPAD; }
     } else if (nm == "feature") { src = t->d_feat; n = (int64_t)B * t->F_stride; }
     else if (nm == "dfeature") { src = t->d_dfeat; n = (int64_t)B * t->F_stride; }
