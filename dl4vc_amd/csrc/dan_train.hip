@@ -667,17 +667,17 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
 // Returns the number of `stats` entries the launch writes (reads for the whole-read form, 64-position tiles for the pointwise one).
 int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
     const bool pointwise = a.mode == 1 && !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
+    static const int n_cus_h = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
     if (pointwise) {
         const long long n_pos = (long long)n_rows * a.L;
         const int tiles = (int)((n_pos + TP_POS - 1) / TP_POS);
         hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
         return tiles;
     }
-    static const int n_cus_h = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
     const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.add2 && !a.addb && !a.stat_aux &&
                             (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS;
     if (half_units) {
@@ -729,63 +729,119 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
         const int site = row / a.R;
         for (int p0 = 0; p0 < L; p0 += WG_CH) {
             __syncthreads();                                     // the previous chunk's MFMAs are done with the images
-            // ---- A rows [p0, p0 + WG_CH): every load of the chunk in flight before the first is consumed (a staging loop of
-            // dependent load -> transform -> LDS store round trips was half of this kernel's time)
+            // ---- A rows [p0, p0 + WG_CH) and B rows [p0 - HALO, p0 + WG_CH + HALO): every load of the chunk -- both operands -- in
+            // flight before the first is consumed (a staging loop of dependent load -> transform -> LDS store round trips was half of
+            // this kernel's time); in the 1x1 forms both operands travel together, ONE memory round trip per chunk.  The per-site
+            // addend of the one pooled layer is a trip of its own.
             {
                 const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * a.a_stride);
                 const v4f* s2 = a.a2 ? (const v4f*)(a.a2 + (size_t)row * L * a.a_stride) : nullptr;
-                constexpr int NIT = (WG_CH * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;       // 7 at 128 channels
-                const Coef3 ck = load_coef(a.a_coef, (tid & (vpa - 1)) * 4);                    // vpa is 32 or 8: i mod vpa == tid mod vpa
-                v4f r1[NIT], r2[NIT];
-#pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    const int i = tid + k * SEG_THREADS;
-                    const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
-                    const bool ok = i < WG_CH * vpa && p < L;
-                    const size_t g = (size_t)p * vpa + c4;
-                    r1[k] = ok ? s1[g] : splat(0.f);
-                    r2[k] = (ok && s2) ? s2[g] : splat(0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    const int i = tid + k * SEG_THREADS;
-                    if (i < WG_CH * vpa) {
-                        const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
-                        const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
-                        *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
-                        bsum += v;
-                    }
-                }
-            }
-            // ---- B rows [p0 - HALO, p0 + WG_CH + HALO)
-            if (a.b_mode == 0) {
-                for (int i = tid; i < BROWS * WG_S / 4; i += SEG_THREADS) ((v4f*)sb)[i] = splat(0.f);
-                __syncthreads();
-                EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
-                encode_rows(sb, WG_S, 0, p0 - HALO, p0 + WG_CH + HALO, e, (size_t)row, site, L, tid);
-            } else {
                 const v4f* b1 = (const v4f*)(a.b1 + (size_t)row * L * CPAD);
-                const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
-                constexpr int NIT = BROWS * (CPAD / 4) / SEG_THREADS;                            // 7
-                static_assert(NIT * SEG_THREADS == BROWS * (CPAD / 4), "B staging covers the image exactly");
-                const Coef3 cb = load_coef(a.b_coef, (tid & 31) * 4);
-                v4f r1[NIT], r2[NIT];
+                constexpr int NIT = (WG_CH * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;       // 7 at 128 channels
+                constexpr int NITB = BROWS * (CPAD / 4) / SEG_THREADS;                           // 7
+                static_assert(NITB * SEG_THREADS == BROWS * (CPAD / 4), "B staging covers the image exactly");
+                const Coef3 ck = load_coef(a.a_coef, (tid & (vpa - 1)) * 4);                    // vpa is 32 or 8: i mod vpa == tid mod vpa
+                // (the same four pieces of code in two orders, written out: behind lambdas hipcc spilled 42 registers of the 3-tap form)
+                if constexpr (TAPS == 1) {
+                    v4f r1[NIT], r2[NIT], rb[NITB];
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    const int i = tid + k * SEG_THREADS;
-                    const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
-                    const bool ok = p >= 0 && p < L;
-                    const size_t g = (size_t)p * (CPAD / 4) + c4;
-                    r1[k] = ok ? b1[g] : splat(0.f);
-                    r2[k] = (ok && pl4) ? pl4[g] : splat(0.f);
-                }
+                    for (int k = 0; k < NIT; ++k) {
+                        const int i = tid + k * SEG_THREADS;
+                        const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                        const bool ok = i < WG_CH * vpa && p < L;
+                        const size_t g = (size_t)p * vpa + c4;
+                        r1[k] = ok ? s1[g] : splat(0.f);
+                        r2[k] = (ok && s2) ? s2[g] : splat(0.f);
+                    }
+                    if (a.b_mode != 0) {
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    const int i = tid + k * SEG_THREADS;
-                    const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
-                    v4f v = r1[k];
-                    if (a.b_coef && p >= 0 && p < L) v = cb.A * v + cb.C;
-                    *(v4f*)(sb + pl * WG_S + c4 * 4) = v + r2[k];
+                        for (int k = 0; k < NITB; ++k) {
+                            const int i = tid + k * SEG_THREADS;
+                            const int p = p0 - HALO + (i >> 5);
+                            rb[k] = (p >= 0 && p < L) ? b1[(size_t)p * (CPAD / 4) + (i & 31)] : splat(0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) {
+                        const int i = tid + k * SEG_THREADS;
+                        if (i < WG_CH * vpa) {
+                            const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                            const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
+                            *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
+                            bsum += v;
+                        }
+                    }
+                    if (a.b_mode == 0) {
+                        for (int i = tid; i < BROWS * WG_S / 4; i += SEG_THREADS) ((v4f*)sb)[i] = splat(0.f);
+                        __syncthreads();
+                        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
+                        encode_rows(sb, WG_S, 0, p0 - HALO, p0 + WG_CH + HALO, e, (size_t)row, site, L, tid);
+                    } else {
+                        const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
+                        const Coef3 cb = load_coef(a.b_coef, (tid & 31) * 4);
+#pragma unroll
+                        for (int k = 0; k < NITB; ++k) {
+                            const int i = tid + k * SEG_THREADS;
+                            const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
+                            const bool in = p >= 0 && p < L;
+                            v4f v = rb[k];
+                            if (a.b_coef && in) v = cb.A * v + cb.C;
+                            if (pl4 && in) v = v + pl4[(size_t)p * (CPAD / 4) + c4];
+                            *(v4f*)(sb + pl * WG_S + c4 * 4) = v;
+                        }
+                    }
+                } else {
+                    // (beside the 96 accumulator registers of the 3-tap form the 21 vectors in flight spill 33 registers and the
+                    // launch takes 1.37 ms instead of 1.19: there B is requested once A is in LDS)
+                    {
+                        v4f r1[NIT], r2[NIT];
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k) {
+                            const int i = tid + k * SEG_THREADS;
+                            const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                            const bool ok = i < WG_CH * vpa && p < L;
+                            const size_t g = (size_t)p * vpa + c4;
+                            r1[k] = ok ? s1[g] : splat(0.f);
+                            r2[k] = (ok && s2) ? s2[g] : splat(0.f);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k) {
+                            const int i = tid + k * SEG_THREADS;
+                            if (i < WG_CH * vpa) {
+                                const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                                const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
+                                *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
+                                bsum += v;
+                            }
+                        }
+                    }
+                    if (a.b_mode == 0) {
+                        for (int i = tid; i < BROWS * WG_S / 4; i += SEG_THREADS) ((v4f*)sb)[i] = splat(0.f);
+                        __syncthreads();
+                        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
+                        encode_rows(sb, WG_S, 0, p0 - HALO, p0 + WG_CH + HALO, e, (size_t)row, site, L, tid);
+                    } else {
+                        const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
+                        const Coef3 cb = load_coef(a.b_coef, (tid & 31) * 4);
+                        v4f rb[NITB], rp[NITB];
+#pragma unroll
+                        for (int k = 0; k < NITB; ++k) {
+                            const int i = tid + k * SEG_THREADS;
+                            const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
+                            const bool ok = p >= 0 && p < L;
+                            const size_t g = (size_t)p * (CPAD / 4) + c4;
+                            rb[k] = ok ? b1[g] : splat(0.f);
+                            rp[k] = (ok && pl4) ? pl4[g] : splat(0.f);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NITB; ++k) {
+                            const int i = tid + k * SEG_THREADS;
+                            const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
+                            v4f v = rb[k];
+                            if (a.b_coef && p >= 0 && p < L) v = cb.A * v + cb.C;
+                            *(v4f*)(sb + pl * WG_S + c4 * 4) = v + rp[k];
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -940,18 +996,29 @@ void launch_wgrad_reduce(const float* partial, const float* bias_partial, int wg
 // ------------------------------------------------------------------------------------------------
 // per-channel statistics: [row][2][CPAD] fp32 partials -> block partials in double -> BatchNorm coefficients
 // ------------------------------------------------------------------------------------------------
-constexpr int STAT_ROWS_PER_BLOCK = 32;
-__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ stats, int n_rows, double* __restrict__ bp) {
-    const int lo = blockIdx.x * STAT_ROWS_PER_BLOCK, hi = min(n_rows, lo + STAT_ROWS_PER_BLOCK);
+// Entries per block: at least 32, and few enough blocks (<= 128) that the single-workgroup kernels behind this one -- which add
+// the block partials in index order, sixteen loads at a time -- wait for eight round trips instead of forty (20 100 tile entries
+// of a pointwise launch: 30 us -> 8 us per layer).
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ stats, int n_rows, int per_block, double* __restrict__ bp) {
+    const int lo = blockIdx.x * per_block, hi = min(n_rows, lo + per_block);
     double sum = 0.0;
-    for (int r = lo; r < hi; ++r) sum += (double)stats[(size_t)r * 2 * CPAD + threadIdx.x];
+    int r = lo;
+    for (; r + 8 <= hi; r += 8) {                               // (eight loads in flight; the additions stay in index order)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = stats[(size_t)(r + j) * 2 * CPAD + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (double)v[j];
+    }
+    for (; r < hi; ++r) sum += (double)stats[(size_t)r * 2 * CPAD + threadIdx.x];
     bp[(size_t)blockIdx.x * 2 * CPAD + threadIdx.x] = sum;
 }
 
 void launch_stats_partial(const float* stats, int n_rows, double* bp, int* n_blocks, hipStream_t s) {
-    const int nb = (n_rows + STAT_ROWS_PER_BLOCK - 1) / STAT_ROWS_PER_BLOCK;
+    const int per_block = std::max(32, (n_rows + 127) / 128);
+    const int nb = (n_rows + per_block - 1) / per_block;
     *n_blocks = nb;
-    hipLaunchKernelGGL(stats_partial_kernel, dim3(nb), dim3(2 * CPAD), 0, s, stats, n_rows, bp);
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(nb), dim3(2 * CPAD), 0, s, stats, n_rows, per_block, bp);
 }
 
 __global__ __launch_bounds__(CPAD) void bn_forward_finalize_kernel(const double* __restrict__ bp, int nb, double n_pos,
@@ -1337,16 +1404,29 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
 constexpr int EMB_W = 2 * EMBED + 2;                            // per token: 20 read-lookup sums, 20 ref-lookup sums, 2 counts
 __global__ __launch_bounds__(512) void embedding_partial_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ reads,
                                                                 const uint8_t* __restrict__ ref, int R, int L, float* __restrict__ partial) {
+    // the row's 40 embedding channels go through LDS first (coalesced 16-byte loads, all in flight at once): the per-(token,
+    // channel) sums below then walk LDS in position order -- the same sums in the same order as a walk over global memory,
+    // which was 201 dependent 4-byte loads per thread (0.40 ms per step at 64 sites; 0.1 ms now)
     __shared__ uint8_t tok[256], rtk[256];
+    __shared__ __attribute__((aligned(16))) float xe[MPOS * 2 * EMBED];
     const int row = blockIdx.x, site = row / R, tid = threadIdx.x;
     if (tid < L) { tok[tid] = min((int)reads[(size_t)row * L + tid], VOCAB - 1); rtk[tid] = min((int)ref[(size_t)site * L + tid], VOCAB - 1); }
+    {
+        constexpr int V = 2 * EMBED / 4;                         // 10 vectors of a position
+        const v4f* xg = (const v4f*)(dx0 + (size_t)row * L * CPAD);
+        for (int i = tid; i < L * V; i += 512) {
+            const int p = i / V, c = i - p * V;
+            ((v4f*)xe)[i] = xg[(size_t)p * (CPAD / 4) + c];
+        }
+    }
     __syncthreads();
     if (tid < VOCAB * EMB_W) {
         const int k = tid / EMB_W, e = tid % EMB_W;
-        const float* x = dx0 + (size_t)row * L * CPAD;
+        const float* x = xe;
+        constexpr int XS = 2 * EMBED;
         float sum = 0.f;
-        if (e < EMBED) { for (int p = 0; p < L; ++p) if (tok[p] == k) sum += x[(size_t)p * CPAD + e]; }
-        else if (e < 2 * EMBED) { for (int p = 0; p < L; ++p) if (rtk[p] == k) sum += x[(size_t)p * CPAD + e]; }
+        if (e < EMBED) { for (int p = 0; p < L; ++p) if (tok[p] == k) sum += x[p * XS + e]; }
+        else if (e < 2 * EMBED) { for (int p = 0; p < L; ++p) if (rtk[p] == k) sum += x[p * XS + e]; }
         else if (e == 2 * EMBED) { for (int p = 0; p < L; ++p) sum += (tok[p] == k); }
         else { if (row == site * R) for (int p = 0; p < L; ++p) sum += (rtk[p] == k); }       // the ref lookup: once per site
         partial[(size_t)row * VOCAB * EMB_W + tid] = sum;
