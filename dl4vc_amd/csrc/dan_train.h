@@ -19,6 +19,7 @@ constexpr int TRAIN_PARTIAL_WGS = 256;    // workgroups of a weight-gradient lau
 // ---- T1: one layer-shaped step on the LDS-resident read -------------------------------------------------------------------
 //   image  = load(mode)                                   encode | rows src1 [affine with src2] [masked by src2 > 0] [+ pool]
 //   acc    = w1 ? GEMM(image; taps, kg, dil) : image
+//            [+ W3 * (src4 > 0 ? src3 : 0)]               (half-read 3-tap launches only)
 //   out1   = [relu](acc + bias1 + add1 + add2 + addb)     rows, CPAD stride;  stats[row] = (sum out1, sum out1 * aux)
 //   out2   = relu(W2 * out1 + bias2)                      the 128 -> 32 bottleneck (rows, HPAD stride), optional
 struct RowArgs {
@@ -44,6 +45,9 @@ struct RowArgs {
     float* out1;                            // rows (CPAD stride) or nullptr
     float* stats;                           // [row][2][CPAD] or nullptr
     const float* stat_aux;                  // rows (CPAD stride): second statistic = sum out1 * aux; nullptr: sum out1^2
+    const float* w3;                        // 3-tap launches on half reads only: a SECOND product added to the accumulators,
+    const float *src3, *src4;               //    W3 (packed [2][8][64][4], K = 32) * (src4 > 0 ? src3 : 0), rows of HPAD floats -- the
+                                            //    bottleneck's transpose rides on the data-gradient launch, which then writes g_{l-1}
     const float* w2;                        // packed bottleneck fragments [8][2][64][4] or nullptr
     const float* bias2;                     // [HPAD]
     float* out2;                            // rows (HPAD stride)

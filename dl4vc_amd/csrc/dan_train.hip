@@ -400,7 +400,41 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
                 for (int n = 0; n < NT; ++n) acc[m][n] = splat(0.f);
             conv_gemm(acc, xs, w, first, a.kg, a.taps, a.dil, lane, 0, cnt);
         }
-        // ---- epilogue: out1 = [relu](acc + bias1); stats[u] = (sum out1, sum out1^2) over the unit's positions
+        if (a.w3) {
+            // ---- the data gradient's consumer adds W_b^T (dh * (h > 0)) to it (and the residual skip, and takes the BatchNorm
+            // statistics): done here, du never crosses HBM (658 MB out, 658 MB in per layer at 64 sites) and the pointwise launch
+            // that did it is gone.  The masked dh rows of the unit take the image's place (channels 0..31 of rows HALO..), the
+            // product is a 1-tap K = 32 walk of the same GEMM core on top of the accumulators.
+            gv4f_ptr w3 = (gv4f_ptr)(a.w3) + (wave * NT) * 64 + lane;
+            const v4f f3[NT] = {w3[0], w3[64]};
+            constexpr int NQ = (MTW * 16 * (HPAD / 4) + RH_THREADS - 1) / RH_THREADS;            // 4 (the last one half used)
+            const v4f* d1 = (const v4f*)(a.src3 + (size_t)row * L * HPAD);
+            const v4f* d2 = (const v4f*)(a.src4 + (size_t)row * L * HPAD);
+            v4f q1[NQ], q2[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int i = tid + k * RH_THREADS;
+                const int p = p0 + (i >> 3);
+                const bool ok = i < MTW * 16 * (HPAD / 4) && p < L;
+                const int g = p * (HPAD / 4) + (i & 7);
+                q1[k] = ok ? d1[g] : splat(0.f);
+                q2[k] = ok ? d2[g] : splat(0.f);
+            }
+            __syncthreads();                                     // every wave has finished reading the image
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int i = tid + k * RH_THREADS;
+                if (i < MTW * 16 * (HPAD / 4)) {
+                    v4f v = q1[k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = q2[k][j] > 0.f ? v[j] : 0.f;
+                    *(v4f*)(xs + (HALO + (i >> 3)) * LDS_S + (i & 7) * 4) = v;
+                }
+            }
+            __syncthreads();
+            conv_gemm(acc, xs, w3, f3, HPAD / 16, 1, 0, lane, 0, cnt);
+        }
+        // ---- epilogue: out1 = [relu](acc + bias1 [+ add2]); stats[u] = (sum out1, sum out1 * (aux or out1)) over the unit's positions
         const size_t rbase = (size_t)row * L * CPAD;
         v4f s0[NT], s1v[NT], bias[NT];
 #pragma unroll
@@ -414,14 +448,19 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
             if (m < cnt && p < L) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
+                    const size_t off = rbase + (size_t)p * CPAD + chb[n];
                     v4f v = acc[m][n] + bias[n];
+                    if (a.add2) v += *(const v4f*)(a.add2 + off);
                     if (a.relu_out) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                     }
-                    s0[n] += v;
-                    s1v[n] += v * v;
-                    *(v4f*)(a.out1 + rbase + (size_t)p * CPAD + chb[n]) = v;
+                    if (a.stats) {
+                        const v4f x = a.stat_aux ? *(const v4f*)(a.stat_aux + off) : v;
+                        s0[n] += v;
+                        s1v[n] += v * x;
+                    }
+                    *(v4f*)(a.out1 + off) = v;
                 }
             }
         }
@@ -678,7 +717,7 @@ int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
         hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
         return tiles;
     }
-    const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.add2 && !a.addb && !a.stat_aux &&
+    const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.addb &&
                             (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS;
     if (half_units) {
         const int n_units = 2 * n_rows, wgs = std::min(n_units, 2 * n_cus_h);

@@ -619,13 +619,16 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
     // final max + mean pool (model.py:824-839)
     launch_final_pool_bwd(t->d_x[NL - 1], t->d_dfeat, t->F_stride, t->d_du, B, R, L, c.c_final, s);
     int cur = 0;                                             // d_g[cur] receives g_l; d_g[cur ^ 1] holds g_{l+1}
+    bool fused_g = false;                                    // the previous iteration's data-gradient launch already wrote g_l into d_g[cur]
     for (int l = NL - 1; l >= 0; --l) {
         const LayerP& lp = t->layers[l];
         const bool next_res = (l + 1 < NL) && t->layers[l + 1].residual;
         const bool pooled = pool_after(c, l + 1);
         float* g = t->d_g[cur];
         const float* g_next = t->d_g[cur ^ 1];
-        {   // g_l = du_{l+1} (or the pool gradient) [+ g_{l+1} through the residual skip] [+ mean_r du_{l+1}] [+ W_b^T (dh_l * (h_l > 0))]
+        if (fused_g) {       // g_l (and its statistics) came out of layer l+1's data-gradient launch, below in the previous iteration
+            fused_g = false;
+        } else {   // g_l = du_{l+1} (or the pool gradient) [+ g_{l+1} through the residual skip] [+ mean_r du_{l+1}] [+ W_b^T (dh_l * (h_l > 0))]
             RowArgs a{};
             a.R = R; a.L = L; a.mode = 1;
             if (H > 0) {
@@ -695,7 +698,19 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             a.w1 = t->pk_conv_d[l]; a.taps = 3; a.kg = KGC; a.dil = lp.dil;
             if (t->wino_layer[l]) { a.w1 = t->pk_wino_d[l]; a.wino = 1; }
             a.out1 = t->d_du;
-            launch_train_row(a, n_rows, s);
+            // g_{l-1} = du_l + W_b^T (dh_{l-1} * (h_{l-1} > 0)) [+ g_l through the residual skip], with the statistics of layer l-1's
+            // BatchNorm backward: folded into this launch (half-read direct form) unless layer l-1 pools -- the read mean of du_l
+            // must exist before g_{l-1} does -- so that du_l is never written
+            if (l > 0 && H > 0 && !pool_after(c, l) && !t->wino_layer[l]) {
+                const LayerP& lq = t->layers[l - 1];
+                a.w3 = t->pk_bot_d[l - 1]; a.src3 = t->d_dh + (size_t)(l - 1) * h_layer; a.src4 = t->d_h + (size_t)(l - 1) * h_layer;
+                a.add2 = lp.residual ? g : nullptr;
+                a.out1 = t->d_g[cur ^ 1];
+                if (!lq.residual) { a.stats = t->d_stats; a.stat_aux = t->d_a[l - 1]; }
+                fused_g = true;
+            }
+            const int e = launch_train_row(a, n_rows, s);
+            if (fused_g && !t->layers[l - 1].residual) stat_entries = e;
         }
         if (l > 0 && pool_after(c, l)) launch_read_mean(t->d_du, t->d_dpool, B, R, L, nullptr, s);     // u_l = x_{l-1} + mean_r x_{l-1}
         cur ^= 1;
