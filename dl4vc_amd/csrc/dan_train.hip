@@ -336,6 +336,11 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
 // data gradient (upper half of the grid or odd workgroups, one to five sleeps: all within 1 %).
 // ------------------------------------------------------------------------------------------------
 constexpr int RH_THREADS = 256, RH_ROWS = MTW * 16 + 2 * HALO;                    // 120 image rows
+// SRC2 / POOL / F2: what the launch carries is known when it is made -- a second source tensor with its mask (the data gradient),
+// the per-site addend (the pooled layer's convolution), the second product (see below) -- and as template parameters the parts a
+// launch does not use cost no instruction: every vector instruction beside the MFMAs is paid for in MFMA issue time (as
+// run-time flags: 1 950 vector instructions per unit beside 1 344 MFMAs).
+template <bool SRC2, bool POOL, bool F2>
 __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, int n_rows, int stagger) {
     __shared__ __attribute__((aligned(16))) float xs[RH_ROWS * LDS_S];
     const int tid0 = threadIdx.x;
@@ -363,10 +368,10 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
             constexpr int NP = RH_ROWS * (CPAD / 4) / RH_THREADS;                   // 15
             static_assert(NP * RH_THREADS == RH_ROWS * (CPAD / 4), "the staging covers the image exactly");
             const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * CPAD);
-            const v4f* s2 = a.src2 ? (const v4f*)(a.src2 + (size_t)row * L * CPAD) : nullptr;
-            const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
+            const v4f* s2 = (const v4f*)(a.src2 + (size_t)row * L * CPAD);
+            const v4f* pl = (const v4f*)(a.pool_in + (size_t)site * L * CPAD);
             const Coef3 ck = load_coef(a.coef, (tid & 31) * 4);     // (i & 31 == tid & 31 in every iteration below)
-            v4f r1[NP], r2[NP], r3[NP];
+            v4f r1[NP], r2[SRC2 ? NP : 1], r3[POOL ? NP : 1];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int i = tid + k * RH_THREADS;
@@ -374,15 +379,22 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
                 const bool ok = p >= 0 && p < L;
                 const int g = p * (CPAD / 4) + (i & 31);
                 r1[k] = ok ? s1[g] : splat(0.f);
-                r2[k] = (ok && s2) ? s2[g] : splat(0.f);
-                r3[k] = (ok && pl) ? pl[g] : splat(0.f);
+                if constexpr (SRC2) r2[k] = ok ? s2[g] : splat(0.f);
+                if constexpr (POOL) r3[k] = ok ? pl[g] : splat(0.f);
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int i = tid + k * RH_THREADS;
-                const int pr = i >> 5, c4 = i & 31, p = p0 - HALO + pr;
-                const bool ok = p >= 0 && p < L;
-                *(v4f*)(xs + pr * LDS_S + c4 * 4) = ok ? apply_transform(r1[k], r2[k], ck, a.coef != nullptr, a.mask_src2) + r3[k] : splat(0.f);
+                const int pr = i >> 5, c4 = i & 31;
+                // (a row outside the window was loaded as zeros: it must be stored as zero, not as the transform's constant term)
+                v4f v = r1[k];
+                if constexpr (SRC2) v = apply_transform(r1[k], r2[k], ck, a.coef != nullptr, a.mask_src2);
+                else if (a.coef) {
+                    const int p = p0 - HALO + pr;
+                    v = (p >= 0 && p < L) ? ck.A * r1[k] + ck.C : splat(0.f);
+                }
+                if constexpr (POOL) v += r3[k];
+                *(v4f*)(xs + pr * LDS_S + c4 * 4) = v;
             }
         }
         __syncthreads();
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
                 for (int n = 0; n < NT; ++n) acc[m][n] = splat(0.f);
             conv_gemm(acc, xs, w, first, a.kg, a.taps, a.dil, lane, 0, cnt);
         }
-        if (a.w3) {
+        if constexpr (F2) {
             // ---- the data gradient's consumer adds W_b^T (dh * (h > 0)) to it (and the residual skip, and takes the BatchNorm
             // statistics): done here, du never crosses HBM (658 MB out, 658 MB in per layer at 64 sites) and the pointwise launch
             // that did it is gone.  The masked dh rows of the unit take the image's place (channels 0..31 of rows HALO..), the
@@ -450,13 +462,14 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
                 for (int n = 0; n < NT; ++n) {
                     const size_t off = rbase + (size_t)p * CPAD + chb[n];
                     v4f v = acc[m][n] + bias[n];
-                    if (a.add2) v += *(const v4f*)(a.add2 + off);
+                    if constexpr (F2) { if (a.add2) v += *(const v4f*)(a.add2 + off); }
                     if (a.relu_out) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                     }
                     if (a.stats) {
-                        const v4f x = a.stat_aux ? *(const v4f*)(a.stat_aux + off) : v;
+                        v4f x = v;
+                        if constexpr (F2) { if (a.stat_aux) x = *(const v4f*)(a.stat_aux + off); }
                         s0[n] += v;
                         s1v[n] += v * x;
                     }
@@ -717,12 +730,19 @@ int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
         hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
         return tiles;
     }
-    const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.addb &&
-                            (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS;
+    const bool f2 = a.w3 != nullptr, src2 = a.src2 != nullptr, pool = a.pool_in != nullptr;
+    const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.addb && (f2 || (!a.add2 && !a.stat_aux)) &&
+                            (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS && !(pool && (src2 || f2)) && !(f2 && !src2) &&
+                            !(a.mask_src2 && !src2);
     if (half_units) {
         const int n_units = 2 * n_rows, wgs = std::min(n_units, 2 * n_cus_h);
         // the second workgroup of a CU starts half a unit late (three s_sleep 127: ~10 us) when there is a second one per CU
-        hipLaunchKernelGGL(train_rowh_kernel, dim3((unsigned)wgs), dim3(RH_THREADS), 0, s, a, n_rows, wgs > n_cus_h ? 3 : 0);
+        const dim3 grid((unsigned)wgs), blk(RH_THREADS);
+        const int st = wgs > n_cus_h ? 3 : 0;
+        if (f2) hipLaunchKernelGGL((train_rowh_kernel<true, false, true>), grid, blk, 0, s, a, n_rows, st);
+        else if (src2) hipLaunchKernelGGL((train_rowh_kernel<true, false, false>), grid, blk, 0, s, a, n_rows, st);
+        else if (pool) hipLaunchKernelGGL((train_rowh_kernel<false, true, false>), grid, blk, 0, s, a, n_rows, st);
+        else hipLaunchKernelGGL((train_rowh_kernel<false, false, false>), grid, blk, 0, s, a, n_rows, st);
         return n_units;
     }
     static const int n_cus = [] {

@@ -7,7 +7,9 @@
 #include <vector>
 #include "dan_train.h"
 namespace dan {
-__global__ void train_rowh_kernel(RowArgs a, int n_rows, int stagger);
+template <bool SRC2, bool POOL, bool F2> __global__ void train_rowh_kernel(RowArgs a, int n_rows, int stagger);
+extern template __global__ void train_rowh_kernel<false, false, false>(RowArgs, int, int);
+extern template __global__ void train_rowh_kernel<true, false, false>(RowArgs, int, int);
 __global__ void train_row_kernel(RowArgs a, int n_rows);
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -36,7 +38,8 @@ int main(int argc, char** argv) {
         for (int it = 0; it < 4; ++it) {
             CK(hipEventRecord(e0));
             if (kind == 0) hipLaunchKernelGGL(train_row_kernel, dim3(grid), dim3(512), 0, 0, b, n_rows);
-            else hipLaunchKernelGGL(train_rowh_kernel, dim3(grid), dim3(256), 0, 0, b, n_rows, stagger);
+            else if (dgrad) hipLaunchKernelGGL((train_rowh_kernel<true, false, false>), dim3(grid), dim3(256), 0, 0, b, n_rows, stagger);
+            else hipLaunchKernelGGL((train_rowh_kernel<false, false, false>), dim3(grid), dim3(256), 0, 0, b, n_rows, stagger);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (it) best = std::min(best, ms);
