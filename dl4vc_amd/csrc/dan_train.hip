@@ -985,9 +985,151 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// T2b: the 1x1 weight gradients (residual 128 x 128, bottleneck 32 x 128) with TWO workgroups per CU.  One tap means 8 (or 2)
+// accumulator tiles per wave instead of 24 and no halo: with chunks of 52 positions both images take 60 KB and a thread stages
+// at most twelve vectors, so the kernel fits 128 registers and two workgroups share a CU -- one stages (these forms are closer
+// to their HBM bound than to their MFMA bound: 1.0-1.3 GB per launch) while the other multiplies.  Unlike the half-output split
+// tried for the 3-tap form nothing is staged twice.  Same arithmetic per chunk as train_wgrad_kernel<1, ...>; the chunk
+// boundaries differ, so the position sums associate differently (fp32, bounded as before by the split-K reduction's own).
+// ------------------------------------------------------------------------------------------------
+constexpr int W1_CH = 52;
+template <bool OWN_O, int CT>
+__global__ __launch_bounds__(SEG_THREADS, 4) void train_wgrad1_kernel(WgradArgs a) {
+    constexpr int NSTEP = W1_CH / 4;                          // 13
+    static_assert(NSTEP % 2 == 1, "the k-step pipeline below runs pairs of steps and one last step");
+    constexpr int NB = OWN_O ? CT : 1, NA = OWN_O ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float sa[W1_CH * WG_S];
+    __shared__ __attribute__((aligned(16))) float sb[W1_CH * WG_S];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.L;
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int vpa = a.a_stride >> 2;
+    v4f acc[NA][NB];
+#pragma unroll
+    for (int x = 0; x < NA; ++x)
+#pragma unroll
+        for (int y = 0; y < NB; ++y) acc[x][y] = splat(0.f);
+    v4f bsum = splat(0.f);
+    for (int i = tid; i < W1_CH * WG_S / 4; i += SEG_THREADS) ((v4f*)sa)[i] = splat(0.f);
+    const bool active = OWN_O ? (wave < a.o_tiles) : (wave < a.c_tiles);
+    for (int row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
+        for (int p0 = 0; p0 < L; p0 += W1_CH) {
+            __syncthreads();                                     // the previous chunk's MFMAs are done with the images
+            {
+                const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * a.a_stride);
+                const v4f* s2 = a.a2 ? (const v4f*)(a.a2 + (size_t)row * L * a.a_stride) : nullptr;
+                const v4f* b1 = (const v4f*)(a.b1 + (size_t)row * L * CPAD);
+                constexpr int NIT = (W1_CH * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;       // 4 (the last one a quarter used)
+                v4f r1[NIT], r2[NIT], rb[NIT];
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
+                    const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                    const bool ok = i < W1_CH * vpa && p < L;
+                    const size_t g = (size_t)p * vpa + c4;
+                    r1[k] = ok ? s1[g] : splat(0.f);
+                    r2[k] = (ok && s2) ? s2[g] : splat(0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
+                    const int p = p0 + (i >> 5);
+                    rb[k] = (i < W1_CH * (CPAD / 4) && p < L) ? b1[(size_t)p * (CPAD / 4) + (i & 31)] : splat(0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
+                    if (i < W1_CH * vpa) {
+                        const int pl = i / vpa, c4 = i - pl * vpa;
+                        v4f v = r1[k];                           // (rows past the window were loaded as zeros; these forms have no affine on A)
+                        if (a.a_mask) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = r2[k][j] > 0.f ? v[j] : 0.f;
+                        }
+                        *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
+                        bsum += v;
+                    }
+                }
+                v4f cbA = splat(1.f), cbC = splat(0.f);
+                if (a.b_coef) { cbA = *(const v4f*)(a.b_coef + (tid & 31) * 4); cbC = *(const v4f*)(a.b_coef + 2 * CPAD + (tid & 31) * 4); }
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int i = tid + k * SEG_THREADS;
+                    if (i < W1_CH * (CPAD / 4)) {
+                        const int pl = i >> 5, c4 = i & 31, p = p0 + pl;
+                        v4f v = rb[k];
+                        if (a.b_coef && p < L) v = cbA * v + cbC;
+                        *(v4f*)(sb + pl * WG_S + c4 * 4) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (active) {
+                const float* pa = sa + kk * WG_S + i16;
+                const float* pb = sb + kk * WG_S + i16;
+                float av[2][NA], bv[2][NB];
+                auto fetch = [&](int k4, float (&A)[NA], float (&B)[NB]) {
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) A[x] = pa[4 * k4 * WG_S + 16 * (OWN_O ? wave : x)];
+#pragma unroll
+                    for (int y = 0; y < NB; ++y) B[y] = pb[4 * k4 * WG_S + 16 * (OWN_O ? y : wave)];
+                };
+                auto mfmas = [&](const float (&A)[NA], const float (&B)[NB]) {
+#pragma unroll
+                    for (int y = 0; y < NB; ++y)
+#pragma unroll
+                        for (int x = 0; x < NA; ++x) acc[x][y] = mfma16(A[x], B[y], acc[x][y]);
+                };
+                fetch(0, av[0], bv[0]);
+                for (int k4 = 0; k4 < NSTEP - 1; k4 += 2) {
+                    fetch(k4 + 1, av[1], bv[1]);
+                    mfmas(av[0], bv[0]);
+                    fetch(k4 + 2, av[0], bv[0]);
+                    mfmas(av[1], bv[1]);
+                }
+                mfmas(av[0], bv[0]);                             // the last (odd) step
+            }
+        }
+    }
+    // ---- partial results of this workgroup
+    const int OP = a.o_tiles * 16, CP = a.c_tiles * 16;
+    if (active) {
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) {
+                const int ot = OWN_O ? wave : x, ct = OWN_O ? y : wave;
+                if (ot >= a.o_tiles || ct >= a.c_tiles) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int o = 16 * ot + 4 * kk + jj, c = 16 * ct + i16;
+                    a.partial[((size_t)blockIdx.x * OP + o) * CP + c] = acc[x][y][jj];
+                }
+            }
+    }
+    __syncthreads();
+    float* scratch = sb;                                         // [SEG_THREADS][4]
+    *(v4f*)(scratch + tid * 4) = bsum;
+    __syncthreads();
+    if (tid < OP) {
+        const int c4 = tid >> 2, j = tid & 3;
+        float sum = 0.f;
+        for (int t = c4; t < SEG_THREADS; t += vpa) sum += scratch[t * 4 + j];
+        a.bias_partial[(size_t)blockIdx.x * OP + tid] = sum;
+    }
+}
+
 int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
     const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
     const dim3 grid((unsigned)wgs), blk(SEG_THREADS);
+    if (a.taps == 1 && a.b_mode != 0 && !a.b_pool && !a.a_coef) {   // 1x1 forms: two workgroups per CU (train_wgrad1_kernel)
+        const int wgs2 = a.n_rows < 2 * TRAIN_PARTIAL_WGS ? a.n_rows : 2 * TRAIN_PARTIAL_WGS;
+        if (a.o_tiles <= 2) hipLaunchKernelGGL((train_wgrad1_kernel<false, 1>), dim3((unsigned)wgs2), blk, 0, s, a);
+        else hipLaunchKernelGGL((train_wgrad1_kernel<true, KGC>), dim3((unsigned)wgs2), blk, 0, s, a);
+        return wgs2;
+    }
     if (a.o_tiles <= 2 && a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, false, 1>), grid, blk, 0, s, a);   // A 32 wide: both its tiles per wave
     else if (a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, true, KGC>), grid, blk, 0, s, a);
     else if (a.c_tiles <= KG0) hipLaunchKernelGGL((train_wgrad_kernel<3, true, KG0>), grid, blk, 0, s, a);

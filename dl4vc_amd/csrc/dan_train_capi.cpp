@@ -393,7 +393,7 @@ int dan_train_finalize(dan_trainer_t* t) {
         (rc = talloc(t, &t->d_dfeatd, (size_t)B * t->F_stride)) || (rc = talloc(t, &t->d_dfeat, (size_t)B * t->F_stride))) return rc;
     if ((rc = talloc(t, &t->d_du, rows * rowf, false)) || (rc = talloc(t, &t->d_g[0], rows * rowf, false)) || (rc = talloc(t, &t->d_g[1], rows * rowf, false)) ||
         (rc = talloc(t, &t->d_dn, rows * rowf, false)) || (rc = talloc(t, &t->d_dpool, (size_t)B * rowf, false))) return rc;
-    if ((rc = talloc(t, &t->d_partial, (size_t)TRAIN_PARTIAL_WGS * 3 * CPAD * CPAD, false)) || (rc = talloc(t, &t->d_bias_partial, (size_t)TRAIN_PARTIAL_WGS * CPAD, false)) ||
+    if ((rc = talloc(t, &t->d_partial, (size_t)TRAIN_PARTIAL_WGS * 3 * CPAD * CPAD, false)) || (rc = talloc(t, &t->d_bias_partial, (size_t)2 * TRAIN_PARTIAL_WGS * CPAD, false)) ||
         (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD + 64 * HPAD, false)) ||
         (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
         (rc = talloc(t, &t->d_clip, 4))) return rc;
