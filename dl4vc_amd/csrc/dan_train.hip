@@ -1121,6 +1121,162 @@ __global__ __launch_bounds__(SEG_THREADS, 4) void train_wgrad1_kernel(WgradArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// T2c: the 3-tap weight gradient with the NEXT chunk's rows in flight under the current chunk's MFMAs.  Same eight waves, same
+// wave tile (one output tile x eight input tiles x three taps: 96 accumulator registers) as train_wgrad_kernel, but chunks of
+// 52 positions in a double-buffered pair of images (2 x 63 KB), so that a thread's share of a chunk is twelve vectors -- few
+// enough to stay in registers through a GEMM that itself touches no global memory (in-order vmcnt: nothing retires them
+// early).  Per chunk: request chunk j + 1 -> multiply chunk j -> transform and store chunk j + 1 into the other image ->
+// barrier.  What stays exposed is the transform and the LDS stores, not the memory round trip.
+// ------------------------------------------------------------------------------------------------
+constexpr int W3_CH = 52;
+template <int CT>
+__global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad3_kernel(WgradArgs a) {
+    constexpr int TAPS = 3;
+    constexpr int BROWS = W3_CH + 2 * HALO;                    // 60
+    constexpr int NSTEP = W3_CH / 4;                          // 13
+    static_assert(NSTEP % 2 == 1, "the k-step pipeline below runs pairs of steps and one last step");
+    __shared__ __attribute__((aligned(16))) float sa[2][W3_CH * WG_S];
+    __shared__ __attribute__((aligned(16))) float sb[2][BROWS * WG_S];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.L;
+    const int i16 = lane & 15, kk = lane >> 4;
+    v4f acc[TAPS][CT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int y = 0; y < CT; ++y) acc[t][y] = splat(0.f);
+    v4f bsum = splat(0.f);
+    const bool active = wave < a.o_tiles;
+    const int n_chunks = (L + W3_CH - 1) / W3_CH;
+    const int my_rows = (a.n_rows - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_items = my_rows * n_chunks;
+    constexpr int NIT = (W3_CH * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;                   // 4 (the last one a quarter used)
+    constexpr int NITB = (BROWS * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;                  // 4 (the last one three quarters used)
+    v4f r1[NIT], r2[NIT], rb[NITB];
+    auto request = [&](int j) {
+        const int row = (int)blockIdx.x + (j / n_chunks) * (int)gridDim.x, p0 = (j % n_chunks) * W3_CH;
+        const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * CPAD);
+        const v4f* s2 = (const v4f*)(a.a2 + (size_t)row * L * CPAD);
+        const v4f* b1 = (const v4f*)(a.b1 + (size_t)row * L * CPAD);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            const int p = p0 + (i >> 5);
+            const bool ok = i < W3_CH * (CPAD / 4) && p < L;
+            const size_t g = (size_t)p * (CPAD / 4) + (i & 31);
+            r1[k] = ok ? s1[g] : splat(0.f);
+            r2[k] = ok ? s2[g] : splat(0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NITB; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            const int p = p0 - HALO + (i >> 5);
+            rb[k] = (i < BROWS * (CPAD / 4) && p >= 0 && p < L) ? b1[(size_t)p * (CPAD / 4) + (i & 31)] : splat(0.f);
+        }
+    };
+    auto stage = [&](int j) {
+        const int p0 = (j % n_chunks) * W3_CH;
+        float* da = sa[j & 1];
+        float* db = sb[j & 1];
+        const Coef3 ck = load_coef(a.a_coef, (tid & 31) * 4);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            if (i < W3_CH * (CPAD / 4)) {
+                const int pl = i >> 5, c4 = i & 31, p = p0 + pl;
+                const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
+                *(v4f*)(da + pl * WG_S + c4 * 4) = v;
+                bsum += v;
+            }
+        }
+        v4f cbA = splat(1.f), cbC = splat(0.f);
+        if (a.b_coef) { cbA = *(const v4f*)(a.b_coef + (tid & 31) * 4); cbC = *(const v4f*)(a.b_coef + 2 * CPAD + (tid & 31) * 4); }
+#pragma unroll
+        for (int k = 0; k < NITB; ++k) {
+            const int i = tid + k * SEG_THREADS;
+            if (i < BROWS * (CPAD / 4)) {
+                const int pl = i >> 5, c4 = i & 31, p = p0 - HALO + pl;
+                v4f v = rb[k];
+                if (a.b_coef && p >= 0 && p < L) v = cbA * v + cbC;
+                *(v4f*)(db + pl * WG_S + c4 * 4) = v;
+            }
+        }
+    };
+    if (n_items > 0) { request(0); stage(0); }
+    __syncthreads();
+    for (int j = 0; j < n_items; ++j) {
+        if (j + 1 < n_items) request(j + 1);                     // in flight under the MFMAs below
+        if (active) {
+            const float* pa = sa[j & 1] + kk * WG_S + i16 + 16 * wave;
+            const float* pb = sb[j & 1] + (HALO + kk) * WG_S + i16;
+            const int dstep = a.dil * WG_S;
+            float av[2], bv[2][TAPS][CT];
+            auto fetch = [&](int k4, float& A, float (&B)[TAPS][CT]) {
+                A = pa[4 * k4 * WG_S];
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int y = 0; y < CT; ++y) B[t][y] = pb[4 * k4 * WG_S + (t - TAPS / 2) * dstep + 16 * y];
+            };
+            auto mfmas = [&](const float& A, const float (&B)[TAPS][CT]) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int y = 0; y < CT; ++y) acc[t][y] = mfma16(A, B[t][y], acc[t][y]);
+            };
+            auto pipeline = [&]() {
+#pragma unroll
+                for (int i = 0; i < TAPS * CT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 1 + TAPS * CT, 0);
+            };
+            fetch(0, av[0], bv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int k4 = 0; k4 < NSTEP - 1; k4 += 2) {
+                fetch(k4 + 1, av[1], bv[1]);
+                mfmas(av[0], bv[0]);
+                pipeline();
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(k4 + 2, av[0], bv[0]);
+                mfmas(av[1], bv[1]);
+                pipeline();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfmas(av[0], bv[0]);                                 // the last (odd) step
+        }
+        if (j + 1 < n_items) stage(j + 1);                       // into the other image: nobody reads it during chunk j
+        __syncthreads();
+    }
+    // ---- partial results of this workgroup
+    const int OP = a.o_tiles * 16, CP = a.c_tiles * 16;
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int y = 0; y < CT; ++y) {
+                if (y >= a.c_tiles) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int o = 16 * wave + 4 * kk + jj, c = 16 * y + i16;
+                    a.partial[(((size_t)blockIdx.x * TAPS + t) * OP + o) * CP + c] = acc[t][y][jj];
+                }
+            }
+    }
+    float* scratch = sb[0];                                      // [SEG_THREADS][4]  (the loop's last barrier freed the images)
+    *(v4f*)(scratch + tid * 4) = bsum;
+    __syncthreads();
+    if (tid < OP) {
+        const int c4 = tid >> 2, j = tid & 3;
+        float sum = 0.f;
+        for (int t = c4; t < SEG_THREADS; t += CPAD / 4) sum += scratch[t * 4 + j];
+        a.bias_partial[(size_t)blockIdx.x * OP + tid] = sum;
+    }
+}
+
 int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
     const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
     const dim3 grid((unsigned)wgs), blk(SEG_THREADS);
@@ -1129,6 +1285,10 @@ int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
         if (a.o_tiles <= 2) hipLaunchKernelGGL((train_wgrad1_kernel<false, 1>), dim3((unsigned)wgs2), blk, 0, s, a);
         else hipLaunchKernelGGL((train_wgrad1_kernel<true, KGC>), dim3((unsigned)wgs2), blk, 0, s, a);
         return wgs2;
+    }
+    if (a.taps == 3 && a.b_mode != 0 && !a.b_pool && a.a2 && a.a_stride == CPAD && a.c_tiles == KGC && a.o_tiles == KGC) {
+        hipLaunchKernelGGL((train_wgrad3_kernel<KGC>), grid, blk, 0, s, a);                    // the next chunk in flight under the MFMAs
+        return wgs;
     }
     if (a.o_tiles <= 2 && a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, false, 1>), grid, blk, 0, s, a);   // A 32 wide: both its tiles per wave
     else if (a.taps == 1) hipLaunchKernelGGL((train_wgrad_kernel<1, true, KGC>), grid, blk, 0, s, a);
