@@ -1921,29 +1921,41 @@ __global__ __launch_bounds__(512) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i][sidx], w[j][sidx], acc[i][j]);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(w[j][sidx], a[i][sidx], acc[i][j]);
         }
         if (kt + 1 < KT) sstore(cur ^ 1);
         __syncthreads();
     }
     (void)Kfull;
+    // The B operand goes FIRST into the MFMA: the result tile is then C^T, a lane holds C[m = .. + r16][n = .. + 4 kk + 0..3] --
+    // four consecutive columns, one 16-byte store (with A first a lane held four ROWS of one column: 4-byte stores, and the
+    // store-bound shapes -- the FC1 weight gradient's 269 MB, the highway's dh -- ran at 1.5-2.6 TB/s).  Same products, same sums.
+    const bool vec = ((N & 3) == 0) && (split_out || ((ldc & 3) == 0));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = bn + wn + j * 16 + r16;
-        if (n >= N) continue;
-        const float b = (bias && !split_out) ? bias[n] : 0.f;
+        const int n0 = bn + wn + j * 16 + kk * 4;
+        if (n0 >= N) continue;
+        v4f b = splat(0.f);
+        if (bias && !split_out) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int jj = 0; jj < 4; ++jj) b[jj] = (n0 + jj < N) ? bias[n0 + jj] : 0.f;
+        }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int m = bm + wm + i * 16 + kk * 4 + jj;
-                if (m < M) {
-                    float v = acc[i][j][jj] + b;
-                    if (split_out) { split_out[((size_t)blockIdx.y * M + m) * N + n] = v; continue; }
-                    if (relu) v = fmaxf(v, 0.f);
-                    C[(size_t)m * ldc + n] = v;
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int m = bm + wm + i * 16 + r16;
+            if (m >= M) continue;
+            v4f v = acc[i][j] + b;
+            if (!split_out && relu) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj], 0.f);
             }
+            float* dst = split_out ? split_out + ((size_t)blockIdx.y * M + m) * N + n0 : C + (size_t)m * ldc + n0;
+            if (vec) *(v4f*)dst = v;
+            else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) if (n0 + jj < N) dst[jj] = v[jj];
+            }
+        }
     }
 }
 
@@ -1963,6 +1975,9 @@ void launch_gemm(const float* A, long long lda, int a_kslow, const float* B, lon
                  float* C, long long ldc, int M, int N, int K, int relu, float* split_ws, long long split_ws_floats, hipStream_t s) {
     const int tiles_m = (M + GM - 1) / GM, tiles_n = (N + GN - 1) / GN, tiles = tiles_m * tiles_n;
     // too few tiles to fill 256 CUs and a long K: split K (deterministic: partials summed in split order)
+    // (More splits do not help the skinny products: FC1's forward takes 166 us at 32, 64 and 256 splits alike -- 189 us + a 66-us
+    // reduction at 256 -- and the highway weight gradient 91 us at 5 splits, 104 us at 10: a k-tile is 128 bytes of each of 128
+    // rows, and that access pattern, not the number of workgroups, sets the rate.)
     int splits = 1;
     if (split_ws && tiles < 64 && K >= 16 * GK) {               // (from K = 512 on: the 10-site step's highway gradients have K = 1000)
         splits = std::min(256 / tiles, K / (8 * GK));
