@@ -103,6 +103,11 @@ void launch_pack_wc(float* dst, const float* src, int H, int L, hipStream_t s);
 // WcT[p][c][o] = Wc[o][c][p] padded to HPAD x HPAD: the operand of launch_highway_bwd
 void launch_pack_wct(float* dst, const float* src, int H, int L, hipStream_t s);
 void launch_pad_copy(float* dst, const float* src, int n, int n_pad, hipStream_t s);
+// one launch for a table of the four job kinds above (type 0 pack_frag: i = taps, kg, tiles, n_out, n_in, flip; l = so, sc, st;
+// 1 pad_copy: i = n, n_pad; 2 pack_wc / 3 pack_wct: i = H, L); first_block = the job's first block of the launch
+struct PackJob { int type, first_block; float* dst; const float* src; int i[6]; long long l[3]; const int *omap, *cmap; };
+int pack_job_blocks(const PackJob& q);
+void launch_pack_jobs(const PackJob* jobs_on_device, int n_jobs, int n_blocks, hipStream_t s);
 
 // ---- pools / highway ---------------------------------------------------------------------------------------------------------------
 // g[site][r][p][c] = dfeat[site][C*L + c*L + p] / R + (r == first argmax_r y[.][r][p][c]) * dfeat[site][c*L + p]

@@ -1452,10 +1452,9 @@ void launch_bn_backward_coef(const double* bp, int n_blocks, double n_pos, const
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_frag_kernel(float* __restrict__ dst, const float* __restrict__ src, int taps, int kg,
-                                                        int tiles, int n_out, int n_in, long long so, long long sc, long long st,
-                                                        int flip, const int* __restrict__ omap, const int* __restrict__ cmap) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_frag_body(long long idx, float* __restrict__ dst, const float* __restrict__ src, int taps, int kg,
+                                               int tiles, int n_out, int n_in, long long so, long long sc, long long st,
+                                               int flip, const int* __restrict__ omap, const int* __restrict__ cmap) {
     const long long total = (long long)taps * kg * tiles * 256;
     if (idx >= total) return;
     const int sidx = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
@@ -1469,6 +1468,11 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(float* __restrict__ dst,
     if (cmap) c = (c < n_in) ? cmap[c] : -1; else if (c >= n_in) c = -1;
     if (o >= 0 && c >= 0) v = src[(long long)o * so + (long long)c * sc + (long long)(flip ? taps - 1 - t : t) * st];
     dst[idx] = v;
+}
+__global__ __launch_bounds__(256) void pack_frag_kernel(float* __restrict__ dst, const float* __restrict__ src, int taps, int kg,
+                                                        int tiles, int n_out, int n_in, long long so, long long sc, long long st,
+                                                        int flip, const int* __restrict__ omap, const int* __restrict__ cmap) {
+    pack_frag_body((long long)blockIdx.x * 256 + threadIdx.x, dst, src, taps, kg, tiles, n_out, n_in, so, sc, st, flip, omap, cmap);
 }
 
 void launch_pack_frag(float* dst, const float* src, int taps, int kg, int tiles, int n_out, int n_in, long long so, long long sc,
@@ -1500,20 +1504,53 @@ void launch_wino_u(float* dst, const float* src, int n_out, int n_in, long long 
 }
 
 // highway kernel fragment order: dst[g = 2p + (c>>4)][n][lane][s] = Wc[o = 16n + (lane&15)][c = 16(g&1) + 4(lane>>4) + s][p]
-__global__ __launch_bounds__(256) void pack_wc_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_wc_body(int idx, float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
     if (idx >= 2 * L * 2 * 256) return;
     const int sidx = idx & 3, lane = (idx >> 2) & 63, n = (idx >> 8) & 1, g = idx >> 9;
     const int o = 16 * n + (lane & 15), c = 16 * (g & 1) + 4 * (lane >> 4) + sidx, p = g >> 1;
     dst[idx] = (o < H && c < H) ? src[((size_t)o * H + c) * L + p] : 0.f;
 }
+__global__ __launch_bounds__(256) void pack_wc_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
+    pack_wc_body(blockIdx.x * 256 + threadIdx.x, dst, src, H, L);
+}
 
 // WcT[p][c][o] = Wc[o][c][p], zero-padded to HPAD x HPAD (the highway backward reads 32 consecutive o per (p, c))
-__global__ __launch_bounds__(256) void pack_wct_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_wct_body(int idx, float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
     if (idx >= L * HPAD * HPAD) return;
     const int o = idx & 31, c = (idx >> 5) & 31, p = idx >> 10;
     dst[idx] = (o < H && c < H) ? src[((size_t)o * H + c) * L + p] : 0.f;
+}
+__global__ __launch_bounds__(256) void pack_wct_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int L) {
+    pack_wct_body(blockIdx.x * 256 + threadIdx.x, dst, src, H, L);
+}
+
+// Every re-packing of a step in ONE launch: the job table is fixed once the trainer is finalized (pointers into the flat
+// parameter buffer and the packed-weight buffers), and ~70 launches of 2-5 us each, one behind the other, were 0.26 ms of every
+// step whatever the batch (3 % of the 10-site step).  Block b serves the job whose block range holds it.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    int j = 0;
+    while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+    const PackJob q = jobs[j];
+    const long long idx = (long long)((int)blockIdx.x - q.first_block) * 256 + threadIdx.x;
+    switch (q.type) {
+    case 0: pack_frag_body(idx, q.dst, q.src, q.i[0], q.i[1], q.i[2], q.i[3], q.i[4], q.l[0], q.l[1], q.l[2], q.i[5], q.omap, q.cmap); break;
+    case 1: if (idx < q.i[1]) q.dst[idx] = idx < q.i[0] ? q.src[idx] : 0.f; break;
+    case 2: pack_wc_body((int)idx, q.dst, q.src, q.i[0], q.i[1]); break;
+    default: pack_wct_body((int)idx, q.dst, q.src, q.i[0], q.i[1]); break;
+    }
+}
+void launch_pack_jobs(const PackJob* jobs, int n_jobs, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, jobs, n_jobs);
+}
+int pack_job_blocks(const PackJob& q) {
+    long long n = 0;
+    switch (q.type) {
+    case 0: n = (long long)q.i[0] * q.i[1] * q.i[2] * 256; break;
+    case 1: n = q.i[1]; break;
+    case 2: n = (long long)2 * q.i[1] * 2 * 256; break;
+    default: n = (long long)q.i[1] * HPAD * HPAD; break;
+    }
+    return (int)((n + 255) / 256);
 }
 
 void launch_pack_wct(float* dst, const float* src, int H, int L, hipStream_t s) {

@@ -71,6 +71,8 @@ struct dan_trainer {
     std::vector<float*> pk_conv_f, pk_conv_d, pk_res_f, pk_res_d, pk_bot_f, pk_bot_d;
     std::vector<float*> pk_wino_f, pk_wino_d;                 // Winograd F(2,3) forms of the conv / its data gradient (dilation-2 layers)
     std::vector<int> wino_layer;
+    PackJob* d_pack_jobs = nullptr;          // the step's re-packing as one launch (build_pack_jobs)
+    int n_pack_jobs = 0, n_pack_blocks = 0;
     std::vector<int> lazy_x;                 // [l] 1: x_l = bn(a_l) is never written -- its consumers form it from a_l as they load
     float* d_xtap = nullptr;                 // scratch for the "act:x<l>" debug tap of such a layer
     float* d_wino_u = nullptr;                                // [128][128][4] scratch of the weight transform
@@ -139,6 +141,7 @@ int talloc(dan_trainer* t, T** p, size_t count, bool zero = true) {
     return DAN_OK;
 }
 
+int build_pack_jobs(dan_trainer* t);
 bool pool_after(const dan_config& c, int l1) { return (c.pool_layers_mask >> l1) & 1u; }
 bool is_residual(const dan_config& c, int l1) {
     return c.residual_start > 0 && l1 >= c.residual_start && !(l1 == c.layers && c.c_init != c.c_final);
@@ -403,6 +406,7 @@ int dan_train_finalize(dan_trainer_t* t) {
     }
     t->split_ws_floats = (long long)32 * B * std::max(t->n0, t->n1);
     if ((rc = talloc(t, &t->d_split_ws, (size_t)t->split_ws_floats, false))) return rc;
+    if ((rc = build_pack_jobs(t))) return rc;
     HIPT(t, hipDeviceSynchronize());
     HIPT(t, hipEventCreateWithFlags(&t->ev_tail, hipEventDisableTiming));
     t->finalized = true;
@@ -424,9 +428,69 @@ void dan_train_destroy(dan_trainer_t* t) {
 namespace {
 
 // weights -> the fragment orders the kernels consume, biases -> padded copies; run at the start of every step
+// The same re-packing as refresh_packed below as a job table for ONE launch (built at finalize: every pointer is fixed by then).
+// The Winograd transforms (opt-in form) go through a scratch buffer and stay separate launches.
+int build_pack_jobs(dan_trainer* t) {
+    const dan_config& c = t->cfg;
+    const int L = c.length, H = c.bottleneck;
+    std::vector<PackJob> jobs;
+    auto frag = [&](float* dst, const float* src, int taps, int kg, int tiles, int n_out, int n_in, long long so, long long sc, long long st,
+                    int flip, const int* omap, const int* cmap) {
+        PackJob q{}; q.type = 0; q.dst = dst; q.src = src; q.i[0] = taps; q.i[1] = kg; q.i[2] = tiles; q.i[3] = n_out; q.i[4] = n_in; q.i[5] = flip;
+        q.l[0] = so; q.l[1] = sc; q.l[2] = st; q.omap = omap; q.cmap = cmap; jobs.push_back(q);
+    };
+    auto pad = [&](float* dst, const float* src, int n, int n_pad) { PackJob q{}; q.type = 1; q.dst = dst; q.src = src; q.i[0] = n; q.i[1] = n_pad; jobs.push_back(q); };
+    auto wc = [&](int type, float* dst, const float* src) { PackJob q{}; q.type = type; q.dst = dst; q.src = src; q.i[0] = H; q.i[1] = L; jobs.push_back(q); };
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerP& lp = t->layers[l];
+        const float* W = pp(t, lp.conv_w);
+        const int* cmap = (l == 0) ? t->d_inv : nullptr;
+        const int cin_canon = (l == 0) ? CIN0 : lp.cin;
+        frag(t->pk_conv_f[l], W, 3, lp.kg, KGC, lp.cout, cin_canon, (long long)lp.cin * 3, 3, 1, 0, nullptr, cmap);
+        frag(t->pk_conv_d[l], W, 3, KGC, KGC, cin_canon, lp.cout, 3, (long long)lp.cin * 3, 1, 1, cmap, nullptr);
+        float* b = t->d_bias + (size_t)l * 3 * CPAD;
+        pad(b, pp(t, lp.conv_b), lp.cout, CPAD);
+        if (lp.residual) {
+            const float* Wr = pp(t, lp.res_w);
+            frag(t->pk_res_f[l], Wr, 1, KGC, KGC, lp.cout, lp.cout, lp.cout, 1, 0, 0, nullptr, nullptr);
+            frag(t->pk_res_d[l], Wr, 1, KGC, KGC, lp.cout, lp.cout, 1, lp.cout, 0, 0, nullptr, nullptr);
+            pad(b + CPAD, pp(t, lp.res_b), lp.cout, CPAD);
+        }
+        if (H > 0) {
+            const float* Wb = pp(t, lp.bot_w);
+            frag(t->pk_bot_f[l], Wb, 1, KGC, 2, H, lp.cout, lp.cout, 1, 0, 0, nullptr, nullptr);
+            frag(t->pk_bot_d[l], Wb, 1, 2, KGC, lp.cout, H, 1, lp.cout, 0, 0, nullptr, nullptr);
+            pad(b + 2 * CPAD, pp(t, lp.bot_b), H, HPAD);
+            wc(2, t->d_wc_pk + (size_t)l * L * 2 * 2 * 256, pp(t, lp.cmp_w));
+            wc(3, t->d_wct + (size_t)l * L * HPAD * HPAD, pp(t, lp.cmp_w));
+            pad(t->d_bc_pad + (size_t)l * HPAD, pp(t, lp.cmp_b), H, HPAD);
+        }
+    }
+    int blocks = 0;
+    for (PackJob& q : jobs) { q.first_block = blocks; blocks += pack_job_blocks(q); }
+    t->n_pack_jobs = (int)jobs.size(); t->n_pack_blocks = blocks;
+    int rc = talloc(t, (uint8_t**)&t->d_pack_jobs, jobs.size() * sizeof(PackJob), false);
+    if (rc) return rc;
+    HIPT(t, hipMemcpy(t->d_pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    return DAN_OK;
+}
+
 void refresh_packed(dan_trainer* t, hipStream_t s) {
     const dan_config& c = t->cfg;
     const int L = c.length, H = c.bottleneck;
+    if (t->d_pack_jobs) {
+        launch_pack_jobs(t->d_pack_jobs, t->n_pack_jobs, t->n_pack_blocks, s);
+        for (int l = 0; l < c.layers; ++l) {
+            if (!t->wino_layer[l]) continue;
+            const LayerP& lp = t->layers[l];
+            const float* W = pp(t, lp.conv_w);
+            launch_wino_u(t->d_wino_u, W, lp.cout, lp.cin, (long long)lp.cin * 3, 3, 0, s);
+            launch_pack_frag(t->pk_wino_f[l], t->d_wino_u, 4, KGC, KGC, lp.cout, lp.cin, (long long)lp.cin * 4, 4, 1, 0, nullptr, nullptr, s);
+            launch_wino_u(t->d_wino_u, W, lp.cin, lp.cout, 3, (long long)lp.cin * 3, 1, s);
+            launch_pack_frag(t->pk_wino_d[l], t->d_wino_u, 4, KGC, KGC, lp.cin, lp.cout, (long long)lp.cout * 4, 4, 1, 0, nullptr, nullptr, s);
+        }
+        return;
+    }
     for (int l = 0; l < c.layers; ++l) {
         const LayerP& lp = t->layers[l];
         const float* W = pp(t, lp.conv_w);
