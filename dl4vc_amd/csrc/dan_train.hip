@@ -2008,8 +2008,161 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
     C[(size_t)m * ldc + n] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FC1 at a FEW sites per GPU (batch 80 over 8 GPUs = 10): three products that each move the 1024 x 73 856 weight matrix (or its
+// gradient) once and do 10 multiply-adds per element -- weight streaming, not matrix work.  On the tiled MFMA kernel they take
+// 130-210 us each (1.3-2 TB/s, at any batch size: its k-tile is 128 bytes of each of 128 rows); here a wave instruction moves ONE
+// KILOBYTE OF ONE ROW and the few-row operand sits in LDS, registers or scalar registers.  M <= 16.
+//   forward        out[b][n]  = sum_k x[b][k] W[n][k]        x slab in LDS, a wave per weight row, lane sums reduced per row
+//   data gradient  dx[b][k]   = sum_n d[b][n] W[n][k]        M accumulator vectors per lane, d[b][n] wave-uniform
+//   weight grad.   gW[n][k]   = sum_b d[b][n] x[b][k]        x slab in registers, rows written as they are formed
+// K-slabs of 1024 floats (a 256-thread workgroup = four 1-KB instructions wide); partials in launch_gemm's split layout.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_MAXM = 16, SK_SLAB = 1024, SK_THREADS = 256, SK_DROWS = 128;
+// sum over the 64 lanes of a wave, every lane gets it: four DPP steps inside the 16-lane rows (one instruction each once the
+// compiler folds the move into the add), two cross-row steps through the permute network
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__global__ __launch_bounds__(SK_THREADS) void fc_skinny_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ W, long long ldw,
+                                                                   float* __restrict__ part, int M, int N, int K, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][SK_SLAB]: sized by the launch, so that 3-4 workgroups share a CU at 10 sites
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * SK_SLAB;
+    for (int i = tid; i < M * (SK_SLAB / 4); i += SK_THREADS) {
+        const int b = i / (SK_SLAB / 4), k = k0 + 4 * (i - b * (SK_SLAB / 4));
+        ((v4f*)xs)[i] = (k < K) ? *(const v4f*)(x + (size_t)b * ldx + k) : splat(0.f);
+    }
+    __syncthreads();
+    const int n_lo = blockIdx.y * rows_per_wg, n_hi = min(N, n_lo + rows_per_wg);
+    auto load_row = [&](int n, v4f (&w)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 4 * (j * 64 + lane);
+            w[j] = (n < n_hi && k < K) ? *(const v4f*)(W + (size_t)n * ldw + k) : splat(0.f);
+        }
+    };
+    v4f w[4], w1[4], w2[4];
+    load_row(n_lo + wave, w);
+    load_row(n_lo + wave + 4, w1);
+    for (int n = n_lo + wave; n < n_hi; n += 4) {
+        load_row(n + 8, w2);                                    // two rows of this wave ahead: they travel under this one's arithmetic
+        float mine = 0.f;
+#pragma unroll
+        for (int b = 0; b < SK_MAXM; ++b) {
+            if (b < M) {
+                v4f a4 = splat(0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a4 += w[j] * *(const v4f*)(xs + b * SK_SLAB + 4 * (j * 64 + lane));
+                const float t = wave_sum((a4[0] + a4[1]) + (a4[2] + a4[3]));
+                mine = (lane == b) ? t : mine;
+            }
+        }
+        if (lane < M) part[((size_t)blockIdx.x * M + lane) * N + n] = mine;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = w1[j]; w1[j] = w2[j]; }
+    }
+}
+
+__global__ __launch_bounds__(SK_THREADS) void fc_skinny_dgrad_kernel(const float* __restrict__ d, long long ldd, const float* __restrict__ W, long long ldw,
+                                                                     float* __restrict__ part, int M, int N, int K, int rows_per_wg) {
+    // out[b][f] = sum over n in this workgroup's rows of d[b][n] W[n][f];  N = output columns (f), K = weight rows (n)
+    // the workgroup's d[b][rows] in LDS (rows_per_wg <= SK_DROWS, a multiple of 4; zero past the range): four rows' factors of a
+    // b are ONE broadcast 16-byte read (as forty scalar loads per four rows the loop waited on the scalar cache every iteration)
+    __shared__ __attribute__((aligned(16))) float ds[SK_MAXM * SK_DROWS];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x * SK_SLAB + 4 * tid;
+    const int n_lo = blockIdx.y * rows_per_wg, n_hi = min(K, n_lo + rows_per_wg);
+    for (int i = tid; i < M * SK_DROWS; i += SK_THREADS) {
+        const int b = i / SK_DROWS, r = i - b * SK_DROWS;
+        ds[i] = (n_lo + r < n_hi) ? d[(size_t)b * ldd + n_lo + r] : 0.f;
+    }
+    __syncthreads();
+    v4f acc[SK_MAXM];
+#pragma unroll
+    for (int b = 0; b < SK_MAXM; ++b) acc[b] = splat(0.f);
+    const bool in = f < N;
+    auto load4 = [&](int n, v4f (&w)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (in && n + r < n_hi) ? *(const v4f*)(W + (size_t)(n + r) * ldw + f) : splat(0.f);
+    };
+    v4f w[4], wn[4];
+    load4(n_lo, w);
+    for (int n = n_lo; n < n_hi; n += 4) {
+        load4(n + 4, wn);
+#pragma unroll
+        for (int b = 0; b < SK_MAXM; ++b) {
+            if (b < M) {
+                const v4f dv = *(const v4f*)(ds + b * SK_DROWS + (n - n_lo));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[b] += splat(dv[r]) * w[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = wn[r];
+    }
+    if (in) {
+#pragma unroll
+        for (int b = 0; b < SK_MAXM; ++b)
+            if (b < M) *(v4f*)(part + ((size_t)blockIdx.y * M + b) * N + f) = acc[b];
+    }
+}
+
+__global__ __launch_bounds__(SK_THREADS) void fc_skinny_wgrad_kernel(const float* __restrict__ d, long long ldd, const float* __restrict__ x, long long ldx,
+                                                                     float* __restrict__ C, long long ldc, int M, int N, int K, int rows_per_wg) {
+    // C[n][f] = sum_b d[b][n] x[b][f];  M = rows n of C, N = columns f, K = the few b
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x * SK_SLAB + 4 * tid;
+    if (f >= N) return;
+    v4f xr[SK_MAXM];
+#pragma unroll
+    for (int b = 0; b < SK_MAXM; ++b) xr[b] = (b < K) ? *(const v4f*)(x + (size_t)b * ldx + f) : splat(0.f);
+    const int n_lo = blockIdx.y * rows_per_wg, n_hi = min(M, n_lo + rows_per_wg);
+    for (int n = n_lo; n < n_hi; ++n) {
+        v4f v = splat(0.f);
+#pragma unroll
+        for (int b = 0; b < SK_MAXM; ++b)
+            if (b < K) v += splat(d[(size_t)b * ldd + n]) * xr[b];
+        *(v4f*)(C + (size_t)n * ldc + f) = v;
+    }
+}
+
 void launch_gemm(const float* A, long long lda, int a_kslow, const float* B, long long ldb, int b_kslow, const float* bias,
                  float* C, long long ldc, int M, int N, int K, int relu, float* split_ws, long long split_ws_floats, hipStream_t s) {
+    // FC1 at a few sites per GPU: the three weight-streaming forms (fc_skinny_*_kernel); vector accesses need the 16-byte
+    // alignment the trainer's padded strides give
+    const bool al = ((lda | ldb | ldc) & 3) == 0;
+    if (split_ws && al && !a_kslow && !b_kslow && M <= SK_MAXM && K >= 8192 && (long long)((K + SK_SLAB - 1) / SK_SLAB) * M * N <= split_ws_floats) {
+        const int slabs = (K + SK_SLAB - 1) / SK_SLAB, groups = std::max(1, std::min(N / 16, (768 + slabs - 1) / slabs));
+        const int rows = (N + groups - 1) / groups;
+        hipLaunchKernelGGL(fc_skinny_fwd_kernel, dim3((unsigned)slabs, (unsigned)((N + rows - 1) / rows)), dim3(SK_THREADS), (size_t)M * SK_SLAB * sizeof(float), s, A, lda, B, ldb, split_ws, M, N, K, rows);
+        hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, split_ws, slabs, bias, C, ldc, M, N, relu);
+        return;
+    }
+    if (split_ws && al && !a_kslow && b_kslow && M <= SK_MAXM && N >= 8192 && (N & 3) == 0 && !bias && !relu) {
+        const int slabs = (N + SK_SLAB - 1) / SK_SLAB;
+        int groups = std::max(1, std::min(K / 16, (768 + slabs - 1) / slabs));
+        while (groups > 1 && (long long)groups * M * N > split_ws_floats) --groups;
+        const int rows = ((K + groups - 1) / groups + 3) & ~3;
+        groups = (K + rows - 1) / rows;
+        if ((long long)groups * M * N <= split_ws_floats && rows <= SK_DROWS) {
+            hipLaunchKernelGGL(fc_skinny_dgrad_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(SK_THREADS), 0, s, A, lda, B, ldb, split_ws, M, N, K, rows);
+            hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, split_ws, groups, bias, C, ldc, M, N, relu);
+            return;
+        }
+    }
+    if (al && a_kslow && b_kslow && K <= SK_MAXM && N >= 8192 && (N & 3) == 0 && !bias && !relu) {
+        const int slabs = (N + SK_SLAB - 1) / SK_SLAB, groups = std::max(1, std::min(M / 16, (768 + slabs - 1) / slabs));
+        const int rows = (M + groups - 1) / groups;
+        hipLaunchKernelGGL(fc_skinny_wgrad_kernel, dim3((unsigned)slabs, (unsigned)((M + rows - 1) / rows)), dim3(SK_THREADS), 0, s, A, lda, B, ldb, C, ldc, M, N, K, rows);
+        return;
+    }
     const int tiles_m = (M + GM - 1) / GM, tiles_n = (N + GN - 1) / GN, tiles = tiles_m * tiles_n;
     // too few tiles to fill 256 CUs and a long K: split K (deterministic: partials summed in split order)
     // (More splits do not help the skinny products: FC1's forward takes 166 us at 32, 64 and 256 splits alike -- 189 us + a 66-us

@@ -404,7 +404,10 @@ int dan_train_finalize(dan_trainer_t* t) {
         t->split_hw_floats = (long long)8 * HPAD * L * HPAD;
         if ((rc = talloc(t, &t->d_dhw, (size_t)NL * rows * HPAD, false)) || (rc = talloc(t, &t->d_split_hw, (size_t)t->split_hw_floats, false))) return rc;
     }
-    t->split_ws_floats = (long long)32 * B * std::max(t->n0, t->n1);
+    // (split-K partials of the FC GEMMs; at <= 16 sites the FC1 forms of fc_skinny_*_kernel: one partial per 1024-float slab of
+    // the feature row forward, up to 12 row groups of the weight matrix in the data gradient)
+    const long long skinny = (long long)std::min(B, 16) * std::max((t->F_stride + 1023) / 1024 * (long long)t->n0, 12 * (long long)t->F_stride);
+    t->split_ws_floats = std::max((long long)32 * B * std::max(t->n0, t->n1), skinny);
     if ((rc = talloc(t, &t->d_split_ws, (size_t)t->split_ws_floats, false))) return rc;
     if ((rc = build_pack_jobs(t))) return rc;
     HIPT(t, hipDeviceSynchronize());
