@@ -121,6 +121,8 @@ void launch_highway_bwd(const float* dfeat, const float* feat, long long fs, int
 void launch_highway_dhw(const float* dfeat, const float* feat, long long fs, int feat_off, float* dhw, int n_sites, int R, int H,
                         int layers, hipStream_t s);
 void launch_highway_wc_transpose(const float* t, float* g_wc, int L, int H, hipStream_t s);
+void launch_highway_bias_grad_all(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial /*[layers][64][HPAD]*/,
+                                  float* g_base, const long long* g_off_on_device, int n_sites, int R, int H, int layers, hipStream_t s);
 void launch_highway_bias_grad(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial /*[64][HPAD]*/,
                               float* g_bc, int n_sites, int R, int H, hipStream_t s);
 // (VALU forms, kept as the reference implementation of the two products)

@@ -1740,23 +1740,30 @@ __global__ __launch_bounds__(256) void highway_bias_partial_kernel(const float* 
                                                                   int feat_off, float* __restrict__ bias_partial, int n_rows, int R, int H) {
     __shared__ float red[8][HPAD];
     const int tid = threadIdx.x, o = tid & 31, lane_row = tid >> 5;
+    // blockIdx.y = layer (every layer of a step in ONE launch; feat_off is layer 0's block of the feature row)
+    const int layer = blockIdx.y;
     const int per = (n_rows + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n_rows, lo + per);
     float sum = 0.f;
     if (o < H)
-        for (int row = lo + lane_row; row < hi; row += 8) sum += dhw_of(dfeat, feat, fs, feat_off, 0, H, R, row, o);
+        for (int row = lo + lane_row; row < hi; row += 8) sum += dhw_of(dfeat, feat, fs, feat_off, layer, H, R, row, o);
     red[lane_row][o] = sum;
     __syncthreads();
     if (tid < HPAD) {
         float t = 0.f;
         for (int i = 0; i < 8; ++i) t += red[i][tid];
-        bias_partial[blockIdx.x * HPAD + tid] = t;
+        bias_partial[((size_t)layer * gridDim.x + blockIdx.x) * HPAD + tid] = t;
     }
 }
 
-__global__ __launch_bounds__(64) void highway_bias_reduce_kernel(const float* __restrict__ bias_partial, int n_blocks, float* __restrict__ g_bc, int H) {
-    const int o = threadIdx.x;
+// g_base + g_off[layer] (or g_bc itself when g_off is null and the grid is one layer): the compression biases' gradients are not
+// contiguous in the flat buffer
+__global__ __launch_bounds__(64) void highway_bias_reduce_kernel(const float* __restrict__ bias_partial, int n_blocks, float* __restrict__ g_bc,
+                                                                 const long long* __restrict__ g_off, int H) {
+    const int o = threadIdx.x, layer = blockIdx.x;
     if (o >= H) return;
-    g_bc[o] = ordered_sum<float>(n_blocks, [&](int b) { return bias_partial[b * HPAD + o]; });
+    const float* bp = bias_partial + (size_t)layer * n_blocks * HPAD;
+    float* dst = g_off ? g_bc + g_off[layer] : g_bc;
+    dst[o] = ordered_sum<float>(n_blocks, [&](int b) { return bp[b * HPAD + o]; });
 }
 
 __global__ __launch_bounds__(256) void highway_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ g_wc, int L, int H) {
@@ -1775,7 +1782,15 @@ void launch_highway_bias_grad(const float* dfeat, const float* feat, long long f
     constexpr int BIAS_BLOCKS = 64;
     const int n_rows = n_sites * R;
     hipLaunchKernelGGL(highway_bias_partial_kernel, dim3(BIAS_BLOCKS), dim3(256), 0, s, dfeat, feat, fs, feat_off, partial, n_rows, R, H);
-    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3(1), dim3(64), 0, s, partial, BIAS_BLOCKS, g_bc, H);
+    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3(1), dim3(64), 0, s, partial, BIAS_BLOCKS, g_bc, (const long long*)nullptr, H);
+}
+// every layer at once: partial [layers][64][HPAD]; the gradient of layer l's bias goes to g_base + g_off[l] (g_off on the device)
+void launch_highway_bias_grad_all(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial, float* g_base,
+                                  const long long* g_off, int n_sites, int R, int H, int layers, hipStream_t s) {
+    constexpr int BIAS_BLOCKS = 64;
+    const int n_rows = n_sites * R;
+    hipLaunchKernelGGL(highway_bias_partial_kernel, dim3(BIAS_BLOCKS, (unsigned)layers), dim3(256), 0, s, dfeat, feat, fs, feat_off, partial, n_rows, R, H);
+    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3((unsigned)layers), dim3(64), 0, s, partial, BIAS_BLOCKS, g_base, g_off, H);
 }
 
 void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, int feat_off, const float* h, long long h_layer,
@@ -1791,7 +1806,7 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
     constexpr int BIAS_BLOCKS = 64;
     float* bias_partial = partial + (size_t)HW_SPLITS * HPAD * n_e;
     hipLaunchKernelGGL(highway_bias_partial_kernel, dim3(BIAS_BLOCKS), dim3(256), 0, s, dfeat, feat, fs, feat_off, bias_partial, n_rows, R, H);
-    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3(1), dim3(64), 0, s, bias_partial, BIAS_BLOCKS, g_bc, H);
+    hipLaunchKernelGGL(highway_bias_reduce_kernel, dim3(1), dim3(64), 0, s, bias_partial, BIAS_BLOCKS, g_bc, (const long long*)nullptr, H);
     (void)layer_stride_b;
 }
 
@@ -2424,11 +2439,23 @@ void launch_heads_bwd(const float* dlogits, const float* hidden, const float* wh
 constexpr int SUMSQ_PER_BLOCK = 256 * 64;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ bp) {
     __shared__ double red[256];
-    const long long lo = (long long)blockIdx.x * SUMSQ_PER_BLOCK;
+    // 16-byte loads, eight in flight (n is a multiple of 4: every tensor of the flat buffer is 16-byte aligned); the squares are
+    // added in double in a fixed order
+    const long long lo4 = (long long)blockIdx.x * (SUMSQ_PER_BLOCK / 4), n4 = n >> 2;
+    const v4f* g4 = (const v4f*)g;
     double sum = 0.0;
-    for (int i = 0; i < 64; ++i) {
-        const long long idx = lo + (long long)i * 256 + threadIdx.x;
-        if (idx < n) { const double v = g[idx]; sum += v * v; }
+#pragma unroll
+    for (int i = 0; i < 16; i += 8) {
+        v4f v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long idx = lo4 + (long long)(i + j) * 256 + threadIdx.x;
+            v[j] = idx < n4 ? g4[idx] : splat(0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += (double)v[j][e] * (double)v[j][e];
     }
     red[threadIdx.x] = sum;
     __syncthreads();
@@ -2471,20 +2498,29 @@ void launch_clip_coef(const double* block_partials, int n_blocks, float clip, fl
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    long long n, const float* __restrict__ clip_out, float lr, float b1, float b2, float eps,
                                                    float bc1, float bc2) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    const float gi = g[idx] * clip_out[1];
-    const float mi = b1 * m[idx] + (1.f - b1) * gi;
-    const float vi = b2 * v[idx] + (1.f - b2) * gi * gi;
-    m[idx] = mi;
-    v[idx] = vi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    p[idx] = p[idx] - (lr / bc1) * (mi / denom);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // one 16-byte vector of each of the four streams per thread
+    if (idx * 4 >= n) return;
+    const float clip = clip_out[1];
+    const v4f g4 = ((const v4f*)g)[idx], m4 = ((const v4f*)m)[idx], v4 = ((const v4f*)v)[idx];
+    v4f p4 = ((const v4f*)p)[idx], mo, vo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gi = g4[e] * clip;
+        const float mi = b1 * m4[e] + (1.f - b1) * gi;
+        const float vi = b2 * v4[e] + (1.f - b2) * gi * gi;
+        mo[e] = mi;
+        vo[e] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p4[e] = p4[e] - (lr / bc1) * (mi / denom);
+    }
+    ((v4f*)m)[idx] = mo;
+    ((v4f*)v)[idx] = vo;
+    ((v4f*)p)[idx] = p4;
 }
 
 void launch_adam(float* p, const float* g, float* m, float* v, long long n, const float* clip_out, float lr, float b1, float b2,
                  float eps, float bc1, float bc2, hipStream_t s) {
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, clip_out, lr, b1, b2, eps, bc1, bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, clip_out, lr, b1, b2, eps, bc1, bc2);
 }
 
 }  // namespace dan

@@ -72,6 +72,7 @@ struct dan_trainer {
     std::vector<float*> pk_wino_f, pk_wino_d;                 // Winograd F(2,3) forms of the conv / its data gradient (dilation-2 layers)
     std::vector<int> wino_layer;
     PackJob* d_pack_jobs = nullptr;          // the step's re-packing as one launch (build_pack_jobs)
+    long long* d_cmpb_off = nullptr;         // [layers] offsets of the compression biases in the flat buffers
     int n_pack_jobs = 0, n_pack_blocks = 0;
     std::vector<int> lazy_x;                 // [l] 1: x_l = bn(a_l) is never written -- its consumers form it from a_l as they load
     float* d_xtap = nullptr;                 // scratch for the "act:x<l>" debug tap of such a layer
@@ -469,6 +470,13 @@ int build_pack_jobs(dan_trainer* t) {
             pad(t->d_bc_pad + (size_t)l * HPAD, pp(t, lp.cmp_b), H, HPAD);
         }
     }
+    if (H > 0) {
+        std::vector<long long> off(c.layers);
+        for (int l = 0; l < c.layers; ++l) off[l] = t->params[t->layers[l].cmp_b].off;
+        int rc2 = talloc(t, &t->d_cmpb_off, off.size(), false);
+        if (rc2) return rc2;
+        HIPT(t, hipMemcpy(t->d_cmpb_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+    }
     int blocks = 0;
     for (PackJob& q : jobs) { q.first_block = blocks; blocks += pack_job_blocks(q); }
     t->n_pack_jobs = (int)jobs.size(); t->n_pack_blocks = blocks;
@@ -680,8 +688,9 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             launch_gemm(dhw, HPAD, 1, t->d_h + (size_t)l * h_layer, NE, 1, nullptr, t->d_hw_partial, NE, HPAD, NE, n_rows, 0, t->d_split_hw,
                         t->split_hw_floats, s);
             launch_highway_wc_transpose(t->d_hw_partial, gp(t, lp.cmp_w), L, H, s);
-            launch_highway_bias_grad(t->d_dfeat, t->d_feat, t->F_stride, hw_off + l * H * R, t->d_bias_partial, gp(t, lp.cmp_b), B, R, H, s);
         }
+        // the compression biases' gradients of all layers (column sums of dhw) in two launches
+        launch_highway_bias_grad_all(t->d_dfeat, t->d_feat, t->F_stride, hw_off, t->d_bias_partial, t->G, t->d_cmpb_off, B, R, H, NL, s);
     }
     // final max + mean pool (model.py:824-839)
     launch_final_pool_bwd(t->d_x[NL - 1], t->d_dfeat, t->F_stride, t->d_du, B, R, L, c.c_final, s);
