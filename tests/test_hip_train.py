@@ -157,42 +157,107 @@ def test_production_width_step_against_oracle():
         otherwise (the step computed the gradient of a network one rounding error away) within a loose 5e-2.
     test_production_width_step_strict_bar_when_no_decision_sits_on_a_rounding_error below moves every decision off its edge and
     holds the same network to the strict bar unconditionally."""
-    cfg = DanConfig(reads=12, fc_sizes=(64, 32))
+    _full_width_step_check(DanConfig(reads=12, fc_sizes=(64, 32)), 5, "production width",
+                           {"label": np.array([0, 2, 1, 0, 2]), "var_type": np.array([1, 0, 2, 2, 0]), "var_base_enum": np.array([1, 2, 5, 8, 3]),
+                            "var_ref_enum": np.array([4, 3, 1, 2, 2]), "is_snp": np.array([1, 1, 0, 0, 1], np.uint8)})
+
+
+def _full_width_step_check(cfg, B, tag, fixed=None):
     sd = random_state_dict(cfg, seed=17)
     for k in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
         sd[k + ".weight"] = (sd[k + ".weight"] * np.float32(0.05)).astype(np.float32)
-    B = 5
     batch = synth.make_sites(B, reads=cfg.reads, seed=18)
     rng = np.random.default_rng(19)
     hp = TrainHyper()
-    tg = {"label": np.array([0, 2, 1, 0, 2]), "var_type": np.array([1, 0, 2, 2, 0]), "allele_freq": rng.random(B).astype(np.float32),
-          "coverage": rng.integers(5, 60, B).astype(np.float32), "var_base_enum": np.array([1, 2, 5, 8, 3]),
-          "var_ref_enum": np.array([4, 3, 1, 2, 2]), "is_snp": np.array([1, 1, 0, 0, 1], np.uint8)}
+    tg = {"allele_freq": rng.random(B).astype(np.float32), "coverage": rng.integers(5, 60, B).astype(np.float32)}
+    if fixed:
+        tg.update(fixed)
+    else:
+        tg.update({"label": rng.integers(0, 3, B), "var_type": rng.integers(0, 3, B), "var_base_enum": rng.integers(1, 9, B),
+                   "var_ref_enum": rng.integers(1, 5, B), "is_snp": rng.integers(0, 2, B).astype(np.uint8)})
     tg["weight"] = example_weights(tg["is_snp"], hp)
-    widths = (cfg.feature_width, 64, 32)
+    widths = (cfg.feature_width, cfg.fc_sizes[0], cfg.fc_sizes[1])
     masks = [(rng.random((B, w)) >= hp.dropout).astype(np.uint8) for w in widths]
     ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
     import torch
     want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64, taps=True)
     w32 = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks)
-    tr = DanTrainer(cfg, hp, max_batch=8).load_state_dict(sd)
+    tr = DanTrainer(cfg, hp, max_batch=max(8, B)).load_state_dict(sd)
     out = tr.train_step(batch.arrays(), tg, dropout_masks=masks)
     for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr"):
-        assert abs(out[k] - float(want[k])) <= 5e-5 * max(1.0, abs(float(want[k]))), (k, out[k], float(want[k]))
+        assert abs(out[k] - float(want[k])) <= 5e-5 * max(1.0, abs(float(want[k]))), (tag, k, out[k], float(want[k]))
     differing = [d for d in decisions_differing(tr, want, cfg, B) if d[2]]
     for kind, l, n, largest in differing:
-        assert largest <= DECISION_MARGIN[kind], "%d %s decisions of layer %d differ from the float64 oracle's, one on an operand of %.3g" % (n, kind, l, largest)
+        assert largest <= DECISION_MARGIN[kind], "%s: %d %s decisions of layer %d differ from the float64 oracle's, one on an operand of %.3g" % (tag, n, kind, l, largest)
     grads = {k[5:]: v for k, v in want.items() if k.startswith("grad:")}
     if not differing:
         assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * float(want["grad_norm"])
         slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
-        worst = check_grads(tr, grads, "production width", slack)
+        worst = check_grads(tr, grads, tag, slack)
     else:
-        worst = check_grads(tr, grads, "production width, %d decisions on rounding edges" % sum(d[2] for d in differing),
+        worst = check_grads(tr, grads, "%s, %d decisions on rounding edges" % (tag, sum(d[2] for d in differing)),
                             {k: 0.5 * (5e-2 - GRAD_RTOL) for k in grads})
-    print("production width: %s; worst gradient %s at %.2g of its max" % (
-        "no decision differs from the float64 oracle's" if not differing else
+    print("%s: %s; worst gradient %s at %.2g of its max" % (
+        tag, "no decision differs from the float64 oracle's" if not differing else
         "decisions on rounding edges that went the other way: " + ", ".join("%s %d: %d (operand <= %.1e)" % d for d in differing), *worst))
+    tr.close()
+
+
+@pytest.mark.parametrize("B", [1, 10, 16, 17])
+def test_fc_stack_products_recomputed_on_the_host(B):
+    """FC1's three products run as weight-streaming kernels up to 16 sites per GPU (csrc/dan_train.hip fc_skinny_*_kernel) and
+    as tiled MFMA GEMMs from 17 on.  Checked here without the conv stack in the way: from the step's own `feature` and `dlogits`
+    taps the FC stack and the heads are recomputed on the host in float64 -- logits (forward), the FC1 weight gradient and
+    `dfeature` (data gradient) must agree to 2e-5 of their max.  (A ReLU input of the FC stack within 1e-6 of zero would make the
+    comparison a coin toss: the case asserts there is none.)"""
+    cfg = DanConfig(reads=2, fc_sizes=(48, 16))
+    sd = random_state_dict(cfg, seed=31)
+    batch = synth.make_sites(B, reads=cfg.reads, seed=32)
+    rng = np.random.default_rng(33)
+    hp = TrainHyper()
+    tg = {"label": rng.integers(0, 3, B), "var_type": rng.integers(0, 3, B), "allele_freq": rng.random(B).astype(np.float32),
+          "coverage": rng.integers(5, 60, B).astype(np.float32), "var_base_enum": rng.integers(1, 9, B),
+          "var_ref_enum": rng.integers(1, 5, B), "is_snp": rng.integers(0, 2, B).astype(np.uint8)}
+    tg["weight"] = example_weights(tg["is_snp"], hp)
+    F = cfg.feature_width
+    assert F >= 8192, "the streaming forms need a long feature row"
+    masks = [(rng.random((B, w)) >= hp.dropout).astype(np.uint8) for w in (F, 48, 16)]
+    tr = DanTrainer(cfg, hp, max_batch=max(8, B)).load_state_dict(sd)
+    tr.backward(batch.arrays(), tg, dropout_masks=masks)
+    fs = tr.query("feature_stride")
+    feat = tr.debug_buffer("feature", B * fs).reshape(B, fs)[:, :F].astype(np.float64)
+    dfeat = tr.debug_buffer("dfeature", B * fs).reshape(B, fs)[:, :F].astype(np.float64)
+    logits = tr.debug_buffer("logits", B * 27).reshape(B, 27).astype(np.float64)
+    dlogits = tr.debug_buffer("dlogits", B * 27).reshape(B, 27).astype(np.float64)
+    fc = sorted((k[:-7] for k in sd if k.startswith("conv2hidden.") and k.endswith(".weight")), key=lambda k: int(k.split(".")[1]))
+    W0, b0, W1, b1 = (sd[fc[0] + ".weight"].astype(np.float64), sd[fc[0] + ".bias"].astype(np.float64),
+                      sd[fc[1] + ".weight"].astype(np.float64), sd[fc[1] + ".bias"].astype(np.float64))
+    heads = ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR")
+    Wh = np.concatenate([sd[h + ".weight"].astype(np.float64) for h in heads], axis=0)
+    bh = np.concatenate([sd[h + ".bias"].astype(np.float64) for h in heads], axis=0)
+    sc = 1.0 / (1.0 - hp.dropout) if hp.dropout > 0 else 1.0
+    m0, m1, m2 = (m.astype(np.float64) * sc for m in masks)
+    featd = feat * m0
+    pre0 = featd @ W0.T + b0
+    hid0d = np.maximum(pre0, 0) * m1
+    pre1 = hid0d @ W1.T + b1
+    hid1d = np.maximum(pre1, 0) * m2
+    assert np.abs(pre0).min() > 1e-6 and np.abs(pre1).min() > 1e-6, "an FC ReLU input sits on a rounding edge: pick another seed"
+    want_logits = hid1d @ Wh.T + bh
+    dhid1 = (dlogits @ Wh) * m2 * (pre1 > 0)
+    dhid0 = (dhid1 @ W1) * m1 * (pre0 > 0)
+    want_gW0 = dhid0.T @ featd
+    want_dfeat = (dhid0 @ W0) * m0
+
+    def close(name, got, want):
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        assert err <= 2e-5, "%s at %d sites: %.3g of its max" % (name, B, err)
+        return err
+    e = (close("logits (FC1 forward)", logits, want_logits),
+         close("FC1 weight gradient", tr.tensor("grad:fc.0.weight", W0.shape).astype(np.float64), want_gW0),
+         close("dfeature (FC1 data gradient)", dfeat, want_dfeat))
+    print("FC stack at %d sites (%s forms): logits %.1e, weight gradient %.1e, dfeature %.1e of their max" % (
+        (B, "streaming" if B <= 16 else "GEMM") + e))
     tr.close()
 
 
