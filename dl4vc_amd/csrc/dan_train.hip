@@ -111,6 +111,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
     __syncthreads();
     constexpr int NP = (MPOS * (CPAD / 4) + SEG_THREADS - 1) / SEG_THREADS;     // 13
     const int vpr = a.s1_stride >> 2;                           // 16-byte vectors per position
+    const int vsh = vpr == 32 ? 5 : 3;                          // (rows are CPAD or HPAD floats wide)
     const int n4 = L * vpr;
     v4f r1[NP], r2[NP];
     auto request = [&](int rw, int tid) {                        // a read's first and second tensor
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
         for (int k = 0; k < NP; ++k) {
             const int i = tid + k * SEG_THREADS;
             if (i < n4) {
-                const int p = i / vpr, c4 = i - p * vpr;
+                const int p = i >> vsh, c4 = i & (vpr - 1);          // (vpr is 32 or 8: a shift, not twenty instructions of integer division)
                 *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = load_transform(r1[k], r2[k], a.coef, c4 * 4, a.mask_src2) + r3[k];
             }
         }
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
     // ---- load the tile (positions beyond the tensor are zero)
     {
         const int vpr = a.s1_stride >> 2;
+        const int vsh = vpr == 32 ? 5 : 3;                      // (rows are CPAD or HPAD floats wide)
         const v4f* s1 = (const v4f*)a.src1 + base * vpr;
         const v4f* s2 = a.src2 ? (const v4f*)a.src2 + base * vpr : nullptr;
         constexpr int NP = TP_POS * (CPAD / 4) / TP_THREADS;        // 8
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
         for (int k = 0; k < NP; ++k) {
             const int i = tid + k * TP_THREADS;
             if (i < TP_POS * vpr) {
-                const int pr = i / vpr, c4 = i - pr * vpr;
+                const int pr = i >> vsh, c4 = i & (vpr - 1);          // (vpr is 32 or 8: shifts -- as a division by a run-time number this line was a third of the kernel's vector instructions)
                 *(v4f*)(xs + pr * LDS_S + c4 * 4) = (pr < n_here) ? apply_transform(r1[k], r2[k], ck, a.coef != nullptr, a.mask_src2) : splat(0.f);
             }
         }
@@ -774,6 +776,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
     const int L = a.L;
     const int i16 = lane & 15, kk = lane >> 4;
     const int vpa = a.a_stride >> 2;
+    const int ash = vpa == 32 ? 5 : 3;                          // (A rows are CPAD or HPAD floats wide: shifts, not integer divisions, in the staging loops)
     v4f acc[TAPS][NA][NB];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
 #pragma unroll
                     for (int k = 0; k < NIT; ++k) {
                         const int i = tid + k * SEG_THREADS;
-                        const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                        const int pl = i >> ash, c4 = i & (vpa - 1), p = p0 + pl;
                         const bool ok = i < WG_CH * vpa && p < L;
                         const size_t g = (size_t)p * vpa + c4;
                         r1[k] = ok ? s1[g] : splat(0.f);
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                     for (int k = 0; k < NIT; ++k) {
                         const int i = tid + k * SEG_THREADS;
                         if (i < WG_CH * vpa) {
-                            const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                            const int pl = i >> ash, c4 = i & (vpa - 1), p = p0 + pl;
                             const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
                             *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
                             bsum += v;
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
 #pragma unroll
                         for (int k = 0; k < NIT; ++k) {
                             const int i = tid + k * SEG_THREADS;
-                            const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                            const int pl = i >> ash, c4 = i & (vpa - 1), p = p0 + pl;
                             const bool ok = i < WG_CH * vpa && p < L;
                             const size_t g = (size_t)p * vpa + c4;
                             r1[k] = ok ? s1[g] : splat(0.f);
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                         for (int k = 0; k < NIT; ++k) {
                             const int i = tid + k * SEG_THREADS;
                             if (i < WG_CH * vpa) {
-                                const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                                const int pl = i >> ash, c4 = i & (vpa - 1), p = p0 + pl;
                                 const v4f v = (p < L) ? apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask) : splat(0.f);
                                 *(v4f*)(sa + pl * WG_S + c4 * 4) = v;
                                 bsum += v;
@@ -1006,6 +1009,7 @@ __global__ __launch_bounds__(SEG_THREADS, 4) void train_wgrad1_kernel(WgradArgs 
     const int L = a.L;
     const int i16 = lane & 15, kk = lane >> 4;
     const int vpa = a.a_stride >> 2;
+    const int ash = vpa == 32 ? 5 : 3;                          // (A rows are CPAD or HPAD floats wide: shifts, not integer divisions, in the staging loops)
     v4f acc[NA][NB];
 #pragma unroll
     for (int x = 0; x < NA; ++x)
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(SEG_THREADS, 4) void train_wgrad1_kernel(WgradArgs 
 #pragma unroll
                 for (int k = 0; k < NIT; ++k) {
                     const int i = tid + k * SEG_THREADS;
-                    const int pl = i / vpa, c4 = i - pl * vpa, p = p0 + pl;
+                    const int pl = i >> ash, c4 = i & (vpa - 1), p = p0 + pl;
                     const bool ok = i < W1_CH * vpa && p < L;
                     const size_t g = (size_t)p * vpa + c4;
                     r1[k] = ok ? s1[g] : splat(0.f);
@@ -1042,7 +1046,7 @@ __global__ __launch_bounds__(SEG_THREADS, 4) void train_wgrad1_kernel(WgradArgs 
                 for (int k = 0; k < NIT; ++k) {
                     const int i = tid + k * SEG_THREADS;
                     if (i < W1_CH * vpa) {
-                        const int pl = i / vpa, c4 = i - pl * vpa;
+                        const int pl = i >> ash, c4 = i & (vpa - 1);
                         v4f v = r1[k];                           // (rows past the window were loaded as zeros; these forms have no affine on A)
                         if (a.a_mask) {
 #pragma unroll
