@@ -737,7 +737,10 @@ int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
                             (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS && !(pool && (src2 || f2)) && !(f2 && !src2) &&
                             !(a.mask_src2 && !src2);
     if (half_units) {
-        const int n_units = 2 * n_rows, wgs = std::min(n_units, 2 * n_cus_h);
+        // as many workgroups as give every one the same number of units (2 000 units at 10 sites: 500 workgroups of 4, not 512 of
+        // which 464 run a fourth round at 94 % idle), an even count (the half a workgroup takes alternates with its round)
+        const int n_units = 2 * n_rows, rounds = (n_units + 2 * n_cus_h - 1) / (2 * n_cus_h);
+        const int wgs = std::min(n_units, ((n_units + rounds - 1) / rounds + 1) & ~1);
         // the second workgroup of a CU starts half a unit late (three s_sleep 127: ~10 us) when there is a second one per CU
         const dim3 grid((unsigned)wgs), blk(RH_THREADS);
         const int st = wgs > n_cus_h ? 3 : 0;
@@ -1282,10 +1285,12 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad3_kernel(Wg
 }
 
 int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
-    const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
+    // (balanced over the rounds: 1 000 rows at 10 sites are 250 workgroups of 4 rows, not 256 of which 232 run a fourth round)
+    auto balanced = [](int n, int cap) { const int rounds = (n + cap - 1) / cap; return (n + rounds - 1) / rounds; };
+    const int wgs = balanced(a.n_rows, TRAIN_PARTIAL_WGS);
     const dim3 grid((unsigned)wgs), blk(SEG_THREADS);
     if (a.taps == 1 && a.b_mode != 0 && !a.b_pool && !a.a_coef) {   // 1x1 forms: two workgroups per CU (train_wgrad1_kernel)
-        const int wgs2 = a.n_rows < 2 * TRAIN_PARTIAL_WGS ? a.n_rows : 2 * TRAIN_PARTIAL_WGS;
+        const int wgs2 = balanced(a.n_rows, 2 * TRAIN_PARTIAL_WGS);
         if (a.o_tiles <= 2) hipLaunchKernelGGL((train_wgrad1_kernel<false, 1>), dim3((unsigned)wgs2), blk, 0, s, a);
         else hipLaunchKernelGGL((train_wgrad1_kernel<true, KGC>), dim3((unsigned)wgs2), blk, 0, s, a);
         return wgs2;
