@@ -29,16 +29,28 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; the bf16x3 path issues 
 PEAK_HBM_GBS = 8000.0
 
 
-def pmc_traffic(section, key):
-    """HBM bytes measured by the newest round's rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs of the same command,
-    committed as profiles/rNN_traffic.json -- counters cannot be collected inside the timed process); None when absent."""
+def pmc_traffic(section, key, source_hash, chunk_sites=None, profiles_dir=None):
+    """(traffic, stale): HBM bytes measured by the newest round's rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs of the
+    same command, committed as profiles/rNN_traffic.json -- counters cannot be collected inside the timed process).
+
+    The figure is reported only when it was measured on THIS code: the section must carry the ``source_hash`` of the library
+    that was profiled (dan_source_hash(), stamped on the PMC run's bench line and copied by tools/summarize_profile.py) and,
+    where the bytes depend on it, the same ``chunk_sites`` as the handle being timed chose (the automatic chunk depends on the
+    device memory that is free at dan_create).  Otherwise (None, True): stale bytes are not evidence.  (None, False) when no
+    capture exists for the section at all."""
     import glob
-    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    tfiles = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r[0-9][0-9]_traffic.json")))
     if not tfiles:
-        return None
+        return None, False
     with open(tfiles[-1]) as f:
         rec = json.load(f).get(section)
-    return int(rec[key]) if rec and key in rec else None
+    if not rec or key not in rec:
+        return None, False
+    if not source_hash or rec.get("source_hash") != source_hash:
+        return None, True
+    if chunk_sites is not None and rec.get("chunk_sites") != chunk_sites:
+        return None, True
+    return int(rec[key]), False
 
 
 def resolve_ranks(args, argv):
@@ -259,12 +271,15 @@ def bench_train(args):
         # algorithmic FLOPs of one step: every GEMM of the forward once more for its data gradient and once for its weight
         # gradient (the layer-1 data gradient IS needed: the embeddings train)
         flops_site = 3.0 * cfg.flops_per_site()
+        from dl4vc_amd import capi
+        build = {"source_hash": capi.source_hash()}
+        traffic, stale = pmc_traffic("train_step_b%d" % B, "hbm_bytes_per_step", build["source_hash"]) if cfg.length == 201 else (None, False)
         value = B * world * args.steps / elapsed
         achieved = value / world * flops_site / 1e12
         line = {"metric": "training sites/sec (DAN train step, 100 reads x %d bp)" % cfg.length, "value": round(value, 2),
                 "unit": "sites/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32", "data": "synthetic", "build": build,
                 "config": {"workload": "one optimisation step (train-mode forward, focal + aux losses, backward, clip, Adam) on %d sites "
                                        "x 100 reads x %d bp per GPU, DAN production network, seeded random weights" % (B, cfg.length),
                            "sites_per_gpu_per_step": B, "reads": 100, "window": cfg.length,
@@ -274,7 +289,7 @@ def bench_train(args):
                            "gflop_per_site": round(flops_site / 1e9, 3)},
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                             "traffic": pmc_traffic("train_step", "hbm_bytes_per_step") if B == 64 and cfg.length == 201 else None,
+                             "traffic": traffic, "traffic_stale": stale,
                              "kernel": "whole step (train_row_kernel + train_wgrad_kernel + train_point_kernel dominate; per-kernel "
                                        "durations and HBM bytes: profiles/rNN_train_kernel_stats.csv, rNN_train_pmc_summary.csv)"},
                 "last_step": {k: round(float(last[k]), 6) for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}}
@@ -470,13 +485,12 @@ def main():
     if rank == 0:
         # HBM traffic of the dominant kernel: measured by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
         # of this same command and committed under profiles/ (PMC collection cannot run inside the timed process)
-        traffic = None
-        if not args.chunk_sites and cfg.reads == 64 and cfg.precision == 0 and cfg.length == 201:
-            traffic = pmc_traffic("segment_kernel_bytes_per_launch", "total")
-        elif not args.chunk_sites and cfg.reads == 128 and cfg.precision == 2 and cfg.length == 301:
-            traffic = pmc_traffic("segmentp_kernel_bytes_per_launch", "total")
-        elif not args.chunk_sites and cfg.reads == 64 and cfg.precision == 1 and cfg.length == 201:
-            traffic = pmc_traffic("segmentx_kernel_bytes_per_launch", "total")
+        from dl4vc_amd import capi
+        build = {"source_hash": capi.source_hash(), "chunk_sites": int(net.handle.query("chunk_sites")),
+                 "chunk_sites_auto": bool(net.handle.query("chunk_sites_auto"))}
+        section = {(0, 64, 201): "segment_kernel_bytes_per_launch", (2, 128, 301): "segmentp_kernel_bytes_per_launch",
+                   (1, 64, 201): "segmentx_kernel_bytes_per_launch"}.get((cfg.precision, cfg.reads, cfg.length))
+        traffic, stale = pmc_traffic(section, "total", build["source_hash"], build["chunk_sites"]) if section else (None, False)
         sites_total = B * world * args.steps
         value = sites_total / elapsed
         # roofline of the dominant kernel (conv-stack segment kernel): algorithmic FLOPs = 2 x MAC of every
@@ -494,7 +508,7 @@ def main():
             "metric": "candidate-variants/sec (DAN fwd, %d reads x %d bp)" % (cfg.reads, cfg.length),
             "value": round(value, 2), "unit": "candidate-variants/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("f32", "bf16x3", "bf16")[cfg.precision], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("f32", "bf16x3", "bf16")[cfg.precision], "data": "synthetic", "build": build,
             "config": {"workload": "synthetic %d sites x %d reads x %d bp per GPU per step, DAN production network "
                                    "(7x conv128 dil2, residual 5-7, read-mean after L2, highway 32, FC %d->1024->256), "
                                    "seeded random weights; `value` = device-resident rate (inputs in HBM before the timed region, "
@@ -506,7 +520,7 @@ def main():
                        "empty_row_fraction": round(float((base.reads.reshape(-1, cfg.length).max(axis=1) == 0).mean()), 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3) if achieved else None,
                          "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
+                         "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic, "traffic_stale": stale,
                          "frac_definition": "algorithmic direct-convolution FLOPs / kernel time / peak (the contract's definition; an "
                                             "EFFECTIVE rate when the Winograd form runs); matrix-pipe utilisation = executed_frac",
                          "conv_algo": "winograd_f23" if cfg.winograd_applies() else "direct",

@@ -16,10 +16,10 @@ from .config import DanConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdl4vc_dan.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/dl4vc_dan.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = ("dan_abi_version", "dan_create", "dan_set_tensor", "dan_finalize", "dan_destroy", "dan_last_error",
+SYMBOLS = ("dan_abi_version", "dan_source_hash", "dan_create", "dan_set_tensor", "dan_finalize", "dan_destroy", "dan_last_error",
            "dan_forward", "dan_forward_aux", "dan_forward_device", "dan_forward_async", "dan_wait", "dan_set_tap", "dan_read_buffer", "dan_query",
            "dan_profile_enable", "dan_kernel_stats")
 
@@ -49,6 +49,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib = C.CDLL(p)
     u8p, f32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_void_p
     lib.dan_abi_version.restype = C.c_int
+    lib.dan_source_hash.restype = C.c_char_p
     lib.dan_create.argtypes = [C.POINTER(DanCConfig), C.POINTER(vp)]
     lib.dan_set_tensor.argtypes = [vp, C.c_char_p, f32p, C.POINTER(C.c_int64), C.c_int32]
     lib.dan_finalize.argtypes = [vp]
@@ -74,6 +75,28 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def source_hash() -> str:
+    """``dan_source_hash()`` of the loaded library: which kernel + C-ABI sources it was built from."""
+    return load_library().dan_source_hash().decode()
+
+
+HASHED_SOURCES = ("dan_*.hip", "dan_*.h", "dan_capi.cpp", "dan_train_capi.cpp")
+
+
+def tree_source_hash(csrc_dir: Optional[str] = None) -> str:
+    """The same digest computed from the sources in the tree (csrc/Makefile: sha256 over the sorted files, 16 hex digits).  Equal to
+    ``source_hash()`` exactly when the library is a build of the tree as it stands."""
+    import glob
+    import hashlib
+    d = csrc_dir or os.path.join(_HERE, "csrc")
+    files = sorted({f for pat in HASHED_SOURCES for f in glob.glob(os.path.join(d, pat))}, key=os.path.basename)
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def c_config(cfg: DanConfig, device_id: int = 0, max_batch: int = 0, chunk_sites: int = 0) -> DanCConfig:

@@ -44,6 +44,7 @@ struct dan_handle {
     int64_t F_stride = 0;                    // padded to a multiple of 16
     int n0_stride = 0;                       // fc_sizes[0] padded to a multiple of 16 (K of the second FC)
     int chunk = 0, max_batch = 0;
+    bool chunk_auto = false;                                   // the chunk was sized by dan_create (free device memory), not by the caller
     int wino = 0;                            // dilation-2 layers in Winograd F(2,3) form
     int tap_layer = -1;
     int last_chunk_sites = 0;
@@ -279,6 +280,11 @@ extern "C" {
 
 int dan_abi_version(void) { return DAN_ABI_VERSION; }
 
+#ifndef DAN_SOURCE_HASH
+#define DAN_SOURCE_HASH "unknown"
+#endif
+const char* dan_source_hash(void) { return DAN_SOURCE_HASH; }
+
 const char* dan_last_error(const dan_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int dan_create(const dan_config* cfg, dan_t** out) {
@@ -331,8 +337,15 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         const double per_site = (double)c.reads * c.length * (CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * elem;
         double budget = 48e9;
         size_t free_b = 0, total_b = 0;
+        // (hipMemGetInfo reports on the CURRENT device: switch for the question, then back -- dan_create leaves the calling
+        // thread's device as it found it; the result depends on what else holds memory at this moment, so the choice is
+        // reported by dan_query("chunk_sites") and measurements key on that, never on the default being a given number)
+        int prev_dev = -1;
+        (void)hipGetDevice(&prev_dev);
         if (hipSetDevice(c.device_id) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
             budget = std::min(budget, (double)free_b / 3.0);
+        if (prev_dev >= 0 && prev_dev != c.device_id) (void)hipSetDevice(prev_dev);
+        h->chunk_auto = true;
         int chunk = 128;
         while (chunk * 2 <= h->max_batch && (double)(chunk * 2) * per_site <= budget) chunk *= 2;
         while (chunk > 1 && (double)chunk * per_site > budget) chunk /= 2;
@@ -896,6 +909,7 @@ int64_t dan_query(const dan_t* h, const char* what) {
     if (w == "feature_width") return h->F;
     if (w == "feature_stride") return h->F_stride;
     if (w == "chunk_sites") return h->chunk;
+    if (w == "chunk_sites_auto") return h->chunk_auto ? 1 : 0;
     if (w == "max_batch") return h->max_batch;
     if (w == "cpad") return CPAD;
     if (w == "tap_sites") return h->last_chunk_sites;

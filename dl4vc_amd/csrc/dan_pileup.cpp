@@ -53,7 +53,11 @@ constexpr int FREVERSE = 0x10;
 
 // ---- BGZF -------------------------------------------------------------------------------------------------------------------------
 struct Bgzf {
-    FILE* f = nullptr;
+    FILE* f = nullptr;                                           // owned: closed with the reader (also when an exception unwinds past it)
+    Bgzf() = default;
+    Bgzf(const Bgzf&) = delete;
+    Bgzf& operator=(const Bgzf&) = delete;
+    ~Bgzf() { if (f) fclose(f); }
     int64_t block_start = 0, next_block = 0;
     std::vector<uint8_t> data, raw;
     size_t off = 0;
@@ -631,8 +635,7 @@ int pe_open(const char* bam_path, const char* bai_path, const char* fasta_path, 
     e->bam_path = bam_path; e->fasta_path = fasta_path; e->opt = *opt;
     {   // both files must open (per-thread handles are opened in pe_encode)
         Bam b;
-        if (!b.open(bam_path)) { const int rc = pe_fail(nullptr, "%s", b.err.c_str()); if (b.r.f) fclose(b.r.f); return rc; }
-        fclose(b.r.f);
+        if (!b.open(bam_path)) return pe_fail(nullptr, "%s", b.err.c_str());
         Fasta f;
         std::string err;
         if (!f.open(fasta_path, err)) return pe_fail(nullptr, "%s", err.c_str());
@@ -664,7 +667,7 @@ int pe_encode(pe_encoder_t* e, const char* const* contigs, const int32_t* positi
         Fasta fasta;
         std::string err;
         if (!bam.open(e->bam_path)) { errors[ti] = bam.err; return; }
-        if (!fasta.open(e->fasta_path, err)) { errors[ti] = err; fclose(bam.r.f); return; }
+        if (!fasta.open(e->fasta_path, err)) { errors[ti] = err; return; }
         Window win;
         win.bam = &bam; win.bai = e->have_bai ? &e->bai : nullptr;
         for (int64_t i = lo; i < hi; ++i) {
@@ -674,7 +677,6 @@ int pe_encode(pe_encoder_t* e, const char* const* contigs, const int32_t* positi
             if (st < 0) { errors[ti] = err.empty() ? "read error" : err; break; }
             status_out[i] = (int8_t)st;
         }
-        fclose(bam.r.f);
       } catch (const std::exception& ex) {
         errors[ti] = std::string("pileup encoder: ") + ex.what();
       } catch (...) {

@@ -54,7 +54,13 @@ struct RowArgs {
 };
 // returns the number of `stats` entries written ([entry][2][CPAD]): reads (the whole-read kernel), half-read units (the 3-tap
 // launches of the direct form: train_rowh_kernel), or 64-position tiles (the pointwise 1x1 launches)
-int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s);
+// Returns the number of `stats` entries the launch writes.  stat_cap: entries a.stats holds -- a launch that would write more is
+// refused BEFORE it is made (TRAIN_ROW_ERR_STATS), as is one whose second product (a.w3) the selected kernel form would ignore
+// (TRAIN_ROW_ERR_FORM).  train_row_fuses_second_product(a): true when `a` (with or without w3 / src3 / src4 set) selects the one
+// form that honours w3 -- the caller decides the g_{l-1} fusion with it.
+constexpr int TRAIN_ROW_ERR_STATS = -2, TRAIN_ROW_ERR_FORM = -3;
+int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s, int stat_cap = 1 << 30);
+bool train_row_fuses_second_product(const RowArgs& a);
 
 // ---- T2: weight gradient  dW[t][o][c] = sum over positions of  A[p][o] * B[p + (t - 1) dil][c]   (+ bias grad = sum A) ------
 struct WgradArgs {

@@ -718,24 +718,40 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
     }
 }
 
-// Returns the number of `stats` entries the launch writes (reads for the whole-read form, 64-position tiles for the pointwise one).
-int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s) {
+// The half-read form's predicate.  With f2 (a.w3 set) the launch must also carry a second source.
+static bool row_half_units(const RowArgs& a, bool f2) {
+    const bool src2 = a.src2 != nullptr, pool = a.pool_in != nullptr;
+    return !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.addb && (f2 || (!a.add2 && !a.stat_aux)) &&
+           (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS && !(pool && (src2 || f2)) && !(f2 && !src2) &&
+           !(a.mask_src2 && !src2);
+}
+bool train_row_fuses_second_product(const RowArgs& a) {
+    const bool pointwise = a.mode == 1 && !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
+    return !pointwise && row_half_units(a, true);
+}
+
+// Returns the number of `stats` entries the launch writes (reads for the whole-read form, half-read units for the half-read form,
+// 64-position tiles for the pointwise one), or TRAIN_ROW_ERR_* without launching.
+int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s, int stat_cap) {
     const bool pointwise = a.mode == 1 && !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
     static const int n_cus_h = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
+    const bool f2 = a.w3 != nullptr, src2 = a.src2 != nullptr, pool = a.pool_in != nullptr;
+    const bool half_units = !pointwise && row_half_units(a, f2);
+    if (f2 && !half_units) return TRAIN_ROW_ERR_FORM;           // only train_rowh_kernel<., ., true> forms the second product
+    {
+        const long long entries = pointwise ? ((long long)n_rows * a.L + TP_POS - 1) / TP_POS : half_units ? 2LL * n_rows : n_rows;
+        if (a.stats && entries > stat_cap) return TRAIN_ROW_ERR_STATS;
+    }
     if (pointwise) {
         const long long n_pos = (long long)n_rows * a.L;
         const int tiles = (int)((n_pos + TP_POS - 1) / TP_POS);
         hipLaunchKernelGGL(train_point_kernel, dim3((unsigned)tiles), dim3(TP_THREADS), 0, s, a, n_pos);
         return tiles;
     }
-    const bool f2 = a.w3 != nullptr, src2 = a.src2 != nullptr, pool = a.pool_in != nullptr;
-    const bool half_units = !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.addb && (f2 || (!a.add2 && !a.stat_aux)) &&
-                            (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS && !(pool && (src2 || f2)) && !(f2 && !src2) &&
-                            !(a.mask_src2 && !src2);
     if (half_units) {
         // as many workgroups as give every one the same number of units (2 000 units at 10 sites: 500 workgroups of 4, not 512 of
         // which 464 run a fourth round at 94 % idle), an even count (the half a workgroup takes alternates with its round)

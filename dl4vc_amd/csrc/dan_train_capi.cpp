@@ -90,6 +90,7 @@ struct dan_trainer {
     std::vector<float*> d_a, d_x, d_pool;
     float* d_h = nullptr;
     float *d_stats = nullptr;
+    int stat_entries_max = 0;                                  // entries d_stats holds (dan_train_finalize); every producer is checked against it
     double* d_bp = nullptr;
     float *d_feat = nullptr, *d_featd = nullptr, *d_hid0 = nullptr, *d_hid0d = nullptr, *d_hid1 = nullptr, *d_hid1d = nullptr;
     float *d_logits = nullptr, *d_dlogits = nullptr, *d_losses = nullptr, *d_site_terms = nullptr;
@@ -122,6 +123,15 @@ int failt(const dan_trainer* t, int code, const char* fmt, ...) {
     va_end(ap);
     if (t) t->err = buf; else g_create_error = buf;
     return code;
+}
+
+// launch_train_row's result: the statistics entries it wrote, or < 0 when it refused (nothing was launched then)
+int check_row_launch(const dan_trainer* t, int entries, const char* what, int layer) {
+    if (entries == TRAIN_ROW_ERR_STATS)
+        return failt(t, DAN_ERR_STATE, "%s launch of layer %d would write more statistics entries than d_stats holds", what, layer + 1);
+    if (entries == TRAIN_ROW_ERR_FORM)
+        return failt(t, DAN_ERR_STATE, "%s launch of layer %d carries a second product (w3) that the selected kernel form ignores", what, layer + 1);
+    return entries < 0 ? failt(t, DAN_ERR_STATE, "%s launch of layer %d refused (%d)", what, layer + 1, entries) : DAN_OK;
 }
 
 #define HIPT(t, call)                                                                            \
@@ -385,7 +395,10 @@ int dan_train_finalize(dan_trainer_t* t) {
         if (pool_after(c, l + 1) && (rc = talloc(t, &t->d_pool[l + 1], (size_t)B * rowf, false))) return rc;
     }
     if (H > 0 && ((rc = talloc(t, &t->d_h, (size_t)NL * rows * L * HPAD, false)) || (rc = talloc(t, &t->d_dh, (size_t)NL * rows * L * HPAD, false)))) return rc;
-    const size_t stat_max = std::max<size_t>(rows, (rows * L + 63) / 64);      // entries: one per read, or per 64-position tile
+    // entries of a statistics pass: one per read (whole-read form), TWO per read (train_rowh_kernel's half-read units, whatever
+    // the window length: at L < 128 that is more than the tiles), or one per 64-position tile (pointwise form)
+    const size_t stat_max = std::max<size_t>(2 * rows, (rows * L + 63) / 64);
+    t->stat_entries_max = (int)stat_max;
     if ((rc = talloc(t, &t->d_stats, stat_max * 2 * CPAD)) || (rc = talloc(t, &t->d_bp, (stat_max / 32 + 2) * 2 * CPAD + (size_t)(t->n_flat / (256 * 64) + 2)))) return rc;
     if ((rc = talloc(t, &t->d_feat, (size_t)B * t->F_stride)) || (rc = talloc(t, &t->d_featd, (size_t)B * t->F_stride)) ||
         (rc = talloc(t, &t->d_hid0, (size_t)B * t->n0_stride)) || (rc = talloc(t, &t->d_hid0d, (size_t)B * t->n0_stride)) ||
@@ -584,6 +597,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
         HIPT(t, hipMemcpyAsync(t->d_tg8, h + n_in, n_tg8, hipMemcpyHostToDevice, s));
         HIPT(t, hipMemcpyAsync(t->d_tgf, h + n_in + n_tg8, o - n_in - n_tg8, hipMemcpyHostToDevice, s));
     }
+    int rc = DAN_OK;
+    const int stat_cap = t->stat_entries_max;
     const bool drop = hp.dropout > 0.f;
     const float dscale = drop ? 1.f / (1.f - hp.dropout) : 1.f;
     const int64_t mcols[3] = {t->F, t->n0, t->n1};
@@ -614,7 +629,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             if (t->wino_layer[l]) { a.w1 = t->pk_wino_f[l]; a.wino = 1; }
             a.bias1 = bias; a.relu_out = 1; a.out1 = t->d_a[l];
             a.stats = c.use_bn ? t->d_stats : nullptr;
-            stat_entries = launch_train_row(a, n_rows, s);
+            stat_entries = launch_train_row(a, n_rows, s, stat_cap);
+            if ((rc = check_row_launch(t, stat_entries, "conv forward", l))) return rc;
         }
         if (c.use_bn) {                                      // batch statistics over (B, R, L) per channel (model.py:750-751, train mode)
             int nb = 0;
@@ -629,7 +645,7 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             if (lp.residual && t->lazy_x[l - 1]) { a.add1 = t->d_a[l - 1]; a.add1_coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
             a.out1 = t->d_x[l];                              // (nullptr for a lazy layer: the launch then only writes h_l)
             if (H > 0) { a.w2 = t->pk_bot_f[l]; a.bias2 = bias + 2 * CPAD; a.out2 = t->d_h + (size_t)l * n_rows * L * HPAD; }
-            launch_train_row(a, n_rows, s);
+            launch_train_row(a, n_rows, s, stat_cap);
         }
         if (pool_after(c, l + 1)) launch_read_mean(t->d_x[l], t->d_pool[l + 1], B, R, L, nullptr, s);
     }
@@ -718,7 +734,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             a.addb = pooled ? t->d_dpool : nullptr;
             a.out1 = g;
             if (!lp.residual) { a.stats = t->d_stats; a.stat_aux = t->d_a[l]; }
-            const int e = launch_train_row(a, n_rows, s);
+            const int e = launch_train_row(a, n_rows, s, stat_cap);
+            if ((rc = check_row_launch(t, e, "g accumulation", l))) return rc;
             if (!lp.residual) stat_entries = e;
         }
         const float* dn = g;
@@ -727,7 +744,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             a.R = R; a.L = L; a.mode = 1; a.src1 = g; a.s1_stride = CPAD;
             a.w1 = t->pk_res_d[l]; a.taps = 1; a.kg = KGC; a.dil = 0;
             a.out1 = t->d_dn; a.stats = t->d_stats; a.stat_aux = t->d_a[l];
-            stat_entries = launch_train_row(a, n_rows, s);
+            stat_entries = launch_train_row(a, n_rows, s, stat_cap);
+            if ((rc = check_row_launch(t, stat_entries, "residual data gradient", l))) return rc;
             dn = t->d_dn;
             WgradArgs w{};
             w.R = R; w.L = L; w.n_rows = n_rows; w.a1 = g; w.a_stride = CPAD;
@@ -777,7 +795,9 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             // g_{l-1} = du_l + W_b^T (dh_{l-1} * (h_{l-1} > 0)) [+ g_l through the residual skip], with the statistics of layer l-1's
             // BatchNorm backward: folded into this launch (half-read direct form) unless layer l-1 pools -- the read mean of du_l
             // must exist before g_{l-1} does -- so that du_l is never written
-            if (l > 0 && H > 0 && !pool_after(c, l) && !t->wino_layer[l]) {
+            // (train_row_fuses_second_product: the launcher's own predicate for the only kernel form that honours w3 -- the two
+            // conditions cannot drift apart, and launch_train_row refuses a w3 it would ignore)
+            if (l > 0 && H > 0 && !pool_after(c, l) && train_row_fuses_second_product(a)) {
                 const LayerP& lq = t->layers[l - 1];
                 a.w3 = t->pk_bot_d[l - 1]; a.src3 = t->d_dh + (size_t)(l - 1) * h_layer; a.src4 = t->d_h + (size_t)(l - 1) * h_layer;
                 a.add2 = lp.residual ? g : nullptr;
@@ -785,7 +805,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
                 if (!lq.residual) { a.stats = t->d_stats; a.stat_aux = t->d_a[l - 1]; }
                 fused_g = true;
             }
-            const int e = launch_train_row(a, n_rows, s);
+            const int e = launch_train_row(a, n_rows, s, stat_cap);
+            if ((rc = check_row_launch(t, e, "conv data gradient", l))) return rc;
             if (fused_g && !t->layers[l - 1].residual) stat_entries = e;
         }
         if (l > 0 && pool_after(c, l)) launch_read_mean(t->d_du, t->d_dpool, B, R, L, nullptr, s);     // u_l = x_{l-1} + mean_r x_{l-1}

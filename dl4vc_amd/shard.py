@@ -9,7 +9,10 @@ from __future__ import annotations
 
 import os
 import shutil
+import zlib
 from typing import List, Tuple
+
+import numpy as np
 
 
 def shard_range(n: int, index: int, count: int) -> Tuple[int, int]:
@@ -50,3 +53,37 @@ def concat_parts(path: str, count: int, header_from: str = None, keep_parts: boo
         for g in range(count):
             os.remove(part_path(path, g))
     return path
+
+
+# ------------------------------------------------------------------------------------------
+# data-parallel replicas: a cheap proof that every rank holds the same parameters
+# ------------------------------------------------------------------------------------------
+PER_REPLICA_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+def replica_checksum(state) -> np.ndarray:
+    """Three numbers that are equal on two ranks exactly when their trained parameters are bit-identical (up to a CRC
+    collision): CRC-32 of every parameter's bytes chained in key order, split into two 16-bit halves (so that a float64
+    all-reduce carries them exactly), and the tensor count.  BatchNorm running statistics are per replica by design
+    (nn.DataParallel keeps replica 0's; main.py:117) and do not take part."""
+    crc, n = 0, 0
+    for key in sorted(state):
+        if key.rsplit(".", 1)[-1] in PER_REPLICA_SUFFIXES:
+            continue
+        crc = zlib.crc32(np.ascontiguousarray(state[key]).tobytes(), crc)
+        n += 1
+    return np.array([crc >> 16, crc & 0xFFFF, n], np.float64)
+
+
+def check_replicas_agree(state, all_reduce_max, what: str = "evaluation") -> None:
+    """Raises when any rank's parameters differ from another's.  ``all_reduce_max(vec)`` -> element-wise maximum over ranks of a
+    float64 vector.  The sharded evaluation scores each rank's share with that rank's parameters: identical by construction
+    (every rank applies the same averaged gradient), and this is the check that the construction held -- a rank that
+    diverged (a skipped step, a non-deterministic reduction) would otherwise score with other weights without any error."""
+    mine = replica_checksum(state)
+    both = np.asarray(all_reduce_max(np.concatenate([mine, -mine])), np.float64)
+    hi, lo = both[:3], -both[3:]
+    if not np.array_equal(hi, lo):
+        raise RuntimeError("%s: the ranks hold different parameters (checksum range %s .. %s, this rank %s); the data-parallel "
+                           "replicas have diverged" % (what, lo.astype(np.int64).tolist(), hi.astype(np.int64).tolist(),
+                                                        mine.astype(np.int64).tolist()))

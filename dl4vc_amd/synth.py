@@ -129,8 +129,8 @@ def make_sites(n_sites: int, reads: int = 64, length: int = 201, seed: int = 0,
 
 
 def _make_sites_generic(n_sites, reads, length, seed, chrom, first_pos) -> SiteBatch:
-    """Windows other than 201 columns (stress shape 128 x 301): SNP-only alleles at column 100, masks
-    written directly (the reference's mask builder is hard-wired to 201 columns, dataset.py:114)."""
+    """Windows other than 201 columns (stress shape 128 x 301): SNP-only alleles at column 100 (the middle column of a window
+    too short to have one), masks written directly (the reference's mask builder is hard-wired to 201 columns, dataset.py:114)."""
     rng = np.random.default_rng(seed)
     B, R, L = n_sites, reads, length
     rf = rng.integers(1, 5, (B, L)).astype(np.uint8)
@@ -140,11 +140,12 @@ def _make_sites_generic(n_sites, reads, length, seed, chrom, first_pos) -> SiteB
     rmask = np.zeros((B, L), np.uint8)
     vmask = np.zeros((B, L), np.uint8)
     recs, nreads = [], np.zeros(B, np.int32)
-    span = int(round(0.75 * L))
+    span = max(2, int(round(0.75 * L)))
+    centre = CENTER if L > CENTER else L // 2
     for b in range(B):
         n = int(np.clip(round(rng.normal(0.78 * R, 0.19 * R)), 1, R))
         nreads[b] = n
-        ref_base = int(rf[b, CENTER])
+        ref_base = int(rf[b, centre])
         alt = int(rng.choice([t for t in (1, 2, 3, 4) if t != ref_base]))
         af = (0.1, 0.5, 1.0)[rng.integers(0, 3)]
         for r in range(n):
@@ -153,14 +154,14 @@ def _make_sites_generic(n_sites, reads, length, seed, chrom, first_pos) -> SiteB
             row = rf[b, lo:hi].copy()
             sub = rng.random(span) < 0.01
             row[sub] = rng.integers(1, 5, int(sub.sum()))
-            if lo < CENTER < hi - 1 and lo != CENTER:
-                row[CENTER - lo] = alt if rng.random() < af else ref_base
+            if lo < centre < hi - 1 and lo != centre:
+                row[centre - lo] = alt if rng.random() < af else ref_base
             row[0], row[-1] = V.START, V.END
             rd[b, r, lo:hi] = row
             ql[b, r, lo:hi] = rng.integers(2, 42, span)
             st[b, r, lo:hi] = rng.integers(1, 3)
-        rmask[b, CENTER] = ref_base
-        vmask[b, CENTER] = alt
+        rmask[b, centre] = ref_base
+        vmask[b, centre] = alt
         recs.append("\t".join((chrom, str(first_pos + 7 * b), ".", _BASES[ref_base - 1], _BASES[alt - 1],
                                "50", ".", "DP=%d;AF=%.4f" % (n, af), "GT:GQ", "1:50")))
     return SiteBatch(rd, ql, st, rf, rmask, vmask, recs, nreads)

@@ -21,8 +21,9 @@ extern "C" {
 #endif
 
 /* ABI history: 1 = first release; 2 = dan_config.conv_algo; 3 = dan_config.skip_empty_rows (struct grows at the end);
- * 4 = dan_forward_async / dan_wait; 5 = dan_config.bf16_form (the library reads no environment variable any more). */
-#define DAN_ABI_VERSION 5
+ * 4 = dan_forward_async / dan_wait; 5 = dan_config.bf16_form (the library reads no environment variable any more);
+ * 6 = dan_source_hash, dan_query("chunk_sites_auto"). */
+#define DAN_ABI_VERSION 6
 #define DAN_MAX_LAYERS 16
 
 typedef enum dan_status {
@@ -77,6 +78,11 @@ typedef struct dan_handle dan_t;
 /* Lifecycle.  Replaces Basic2DNet(**flags) -> load_state_dict() -> eval()
  * (main.py:99-124, trainer.py:476). */
 int dan_abi_version(void);
+/* Identity of the kernel + C-ABI sources this library was built from (first 16 hex digits of their sha256, set by
+ * dl4vc_amd/csrc/Makefile; "unknown" for a build that did not pass it).  Measurement plumbing: bench.py stamps it on its line
+ * and reports profiled HBM traffic only when profiles/rNN_traffic.json was captured with the same sources.  No counterpart in
+ * the reference. */
+const char* dan_source_hash(void);
 int dan_create(const dan_config* cfg, dan_t** out);
 /* One checkpoint tensor by its state-dict name WITHOUT the "module." prefix (main.py:117,196), fp32,
  * C-contiguous, host memory; copied.  Names: SURVEY.md section 8b "Weights contract".  The two

@@ -90,6 +90,7 @@ def train_main(args, argv) -> int:
     from dl4vc_amd.model import DanNet, load_checkpoint
     from dl4vc_amd.vcf import start_scored_vcf, scored_vcf_path
     from dl4vc_amd.inference import select_sites
+    from dl4vc_amd.shard import check_replicas_agree
     from dl4vc_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,6 +186,15 @@ def train_main(args, argv) -> int:
             if dist is not None:
                 import torch
                 on_gpu = dist.get_backend() == "nccl"
+
+                def all_reduce_max(vec):
+                    t = torch.from_numpy(np.asarray(vec, np.float64).copy())
+                    if on_gpu:
+                        t = t.cuda()
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return t.cpu().numpy()
+                # the assumption the broadcast below rests on, checked: one all-reduce of six numbers per evaluation
+                check_replicas_agree(state, all_reduce_max, "epoch %d evaluation" % epoch)
                 for key in sorted(k for k in state if k.startswith("bn1D_layers.") and
                                   k.rsplit(".", 1)[1] in ("running_mean", "running_var", "num_batches_tracked")):
                     v = np.ascontiguousarray(state[key])

@@ -207,6 +207,46 @@ def test_eight_rank_sharding_with_a_remainder_equals_single_process(hdf_1k, tmp_
     assert not any(os.path.exists(part_path(multi, r)) for r in range(8))
 
 
+def _replica_rank_main(rank, world, port, diverge, out_dir):
+    import torch
+    import torch.distributed as dist
+    from dl4vc_amd.shard import check_replicas_agree
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    state = random_state_dict(SMALL, seed=2)
+    for i, k in enumerate(k for k in sorted(state) if k.endswith("running_mean")):
+        state[k] = state[k] + np.float32(rank)                  # per replica by design: never part of the check
+    if diverge and rank == world - 1:
+        k = sorted(k for k in state if k.endswith(".weight"))[3]
+        v = state[k].copy()
+        v.flat[v.size // 2] = np.nextafter(v.flat[v.size // 2], np.float32(np.inf))   # ONE ulp in one element
+        state[k] = v
+
+    def all_reduce_max(vec):
+        t = torch.from_numpy(np.asarray(vec, np.float64).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.numpy()
+    try:
+        check_replicas_agree(state, all_reduce_max)
+        verdict = "agree"
+    except RuntimeError as e:
+        verdict = "diverged" if "diverged" in str(e) else "other: %s" % e
+    open(os.path.join(out_dir, "rank%d" % rank), "w").write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("diverge", [False, True])
+def test_sharded_evaluation_checks_that_the_replicas_hold_the_same_parameters(tmp_path, diverge):
+    """main.py's sharded evaluation broadcasts only the BatchNorm running statistics and scores every rank's share with that
+    rank's own parameters: one all-reduce of a parameter checksum proves they are the same bits -- a one-ulp
+    difference in one element on one of three ranks is an error ON EVERY RANK (no rank walks into the evaluation alone)."""
+    import torch.multiprocessing as mp
+    port = 25500 + (os.getpid() % 2000) + int(diverge)
+    mp.spawn(_replica_rank_main, args=(3, port, diverge, str(tmp_path)), nprocs=3, join=True)
+    got = [open(str(tmp_path / ("rank%d" % r))).read() for r in range(3)]
+    assert got == ["diverged" if diverge else "agree"] * 3, got
+
+
 def test_shard_arithmetic_at_genome_scale():
     """The partition of a whole-genome candidate set (~4 M sites; the training set of config 4: 77.7 M
     gradient floats exchanged in 1/8 chunks) over 8 ranks: contiguous, exhaustive, sizes differ by at most one, for counts 8

@@ -472,7 +472,7 @@ def test_split_step_and_gradient_buckets():
     tr.close()
 
 
-def random_train_case(seed):
+def random_train_case(seed, length=None, reads=None, sites=None):
     """A seeded random network structure + batch + targets + dropout masks for the training step."""
     rng = np.random.default_rng(7000 + seed)
     layers = int(rng.integers(1, 8))
@@ -487,11 +487,15 @@ def random_train_case(seed):
               fc_sizes=(int(rng.choice([8, 24, 40])), int(rng.choice([4, 12]))), use_bn=bool(rng.integers(0, 4) > 0),
               use_q=bool(rng.integers(0, 2)), use_strand=bool(rng.integers(0, 2)), use_mask=bool(rng.integers(0, 2)),
               dil_mid=int(rng.choice([1, 2, 2, 3])), dil_final=int(rng.choice([1, 2, 2, 4])))
+    if length is not None:
+        kw["length"] = length
+    if reads is not None:
+        kw["reads"] = reads
     cfg = DanConfig(**kw)
     sd = random_state_dict(cfg, seed=8000 + seed)
     for k in ("fcHidden2BinTarget", "fcHidden2VT", "fcHidden2AF", "fcHidden2Coverage", "fcHidden2VB", "fcHidden2VR"):
         sd[k + ".weight"] = (sd[k + ".weight"] * np.float32(0.1)).astype(np.float32)
-    B = int(rng.integers(1, 6))
+    B = int(rng.integers(1, 6)) if sites is None else sites
     batch = synth.make_sites(B, reads=cfg.reads, length=cfg.length, seed=9000 + seed)
     hp = TrainHyper(dropout=float(rng.choice([0.0, 0.1, 0.3])), grad_clip=float(rng.choice([0.0, 1.0])),
                     fp_train_weight=float(rng.choice([0.2, 1.0])), focal_gamma=float(rng.choice([0.0, 0.2, 2.0])),
@@ -505,9 +509,9 @@ def random_train_case(seed):
     return kw, cfg, sd, batch, hp, tg, masks
 
 
-def run_random_train_case(seed):
+def run_random_train_case(seed, **shape):
     import torch
-    kw, cfg, sd, batch, hp, tg, masks = random_train_case(seed)
+    kw, cfg, sd, batch, hp, tg, masks = random_train_case(seed, **shape)
     ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
     want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64)
     w32 = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks)
@@ -531,6 +535,15 @@ def test_random_structures_train_step_against_float64_oracle(seed):
     against the training oracle in float64 (1e-4 of the tensor's max plus twice the fp32 oracle's own distance from it).
     tests/diagnostics/fuzz_train.py runs the same check over a wider seed range."""
     run_random_train_case(seed)
+
+
+@pytest.mark.parametrize("seed,length,reads,sites", [(20, 64, 13, 6), (21, 40, 9, 8), (22, 100, 16, 7), (23, 8, 5, 3), (24, 127, 11, 6)])
+def test_short_windows_train_step_against_float64_oracle(seed, length, reads, sites):
+    """Windows below 128 columns.  The half-read row kernel writes TWO statistics entries per read whatever the window length,
+    which at L < 128 is more than one per 64-position tile: d_stats was once sized for max(reads, tiles) and every BatchNorm pass
+    of such a shape wrote and read past its end (no fixture or random case had L < 112).  Rows x 2 exceeds the old
+    size in every case here; the gradients are held to the float64 oracle like the other random structures."""
+    run_random_train_case(seed, length=length, reads=reads, sites=sites)
 
 
 def test_data_parallel_average_equals_the_full_batch_gradient():

@@ -41,6 +41,28 @@ def counters(path):
     return {k: {c: list(d.values()) for c, d in cs.items()} for k, cs in per.items()}
 
 
+def build_of(json_path):
+    """The ``build`` object ({source_hash, chunk_sites, ...}) of the bench line a profiled run printed; {} when absent."""
+    if not os.path.isfile(json_path):
+        return {}
+    ls = [l for l in open(json_path) if l.startswith("{")]
+    return json.loads(ls[-1]).get("build", {}) if ls else {}
+
+
+def tree_identity():
+    """Where the summary was made: git HEAD (+ "-dirty" when tracked files differ) and the source hash of the tree as it stands."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    from dl4vc_amd import capi
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+        if subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "dl4vc_amd/csrc"]).returncode:
+            head += "-dirty"
+    except Exception:
+        head = "unknown"
+    return {"git_head_at_summary": head, "tree_source_hash_at_summary": capi.tree_source_hash()}
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
@@ -83,8 +105,14 @@ def main():
             if "segment_kernel" in k:
                 seg_bytes[c] = sum(v) / len(v) * 1024.0
     fetch = 2.0 * seg_bytes["FETCH_SIZE"]
+    traffic.update(tree_identity())
+    b_f, b_w = build_of(os.path.join(src, "FETCH_SIZE.json")), build_of(os.path.join(src, "WRITE_SIZE.json"))
+    if b_f.get("source_hash") != b_w.get("source_hash"):
+        raise SystemExit("the FETCH_SIZE and WRITE_SIZE passes ran on different builds")
+    # bench.py reports `traffic` only for a library with this source_hash whose handle chose this chunk (bench.py::pmc_traffic)
     traffic["segment_kernel_bytes_per_launch"] = {"fetch_corrected": fetch, "write": seg_bytes["WRITE_SIZE"],
-                                                  "total": fetch + seg_bytes["WRITE_SIZE"]}
+                                                  "total": fetch + seg_bytes["WRITE_SIZE"],
+                                                  "source_hash": b_f.get("source_hash"), "chunk_sites": b_f.get("chunk_sites")}
     n_disp = max(d["dispatches"] for k, d in traffic["per_kernel"]["WRITE_SIZE"].items() if "segment_kernel" in k)
     # the PMC bench runs 4096 sites, 2 segment launches per chunk -- once for the timed pass and once more when the line carries
     # the host_path pass (same chunking)
@@ -100,7 +128,9 @@ def main():
         json.dump(traffic, out, indent=1)
     # the profiled run printed its line before these counters existed: carry the traffic measured for the same command
     rec = json.loads(line)
-    rec["roofline"]["traffic"] = int(fetch + seg_bytes["WRITE_SIZE"])
+    if rec.get("build", {}).get("source_hash") == b_f.get("source_hash") and rec.get("build", {}).get("chunk_sites") == b_f.get("chunk_sites"):
+        rec["roofline"]["traffic"] = int(fetch + seg_bytes["WRITE_SIZE"])
+        rec["roofline"]["traffic_stale"] = False
     with open(os.path.join(dst, tag + "_bench_line_under_rocprof.json"), "w") as out:
         out.write(json.dumps(rec) + "\n")
 
@@ -145,6 +175,7 @@ def extras(tag, dst):
                 out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 %s   (kernel_stats.csv, verbatim)\n" % what)
                 out.write(open(hits[-1]).read())
     pmc = {"train": ("--mode train --steps 2 --warmup 1 --no-cpu-baseline", 3),
+           "train_b10": ("--mode train --train-batch 10 --steps 2 --warmup 1 --no-cpu-baseline", 3),
            "bf16": ("--precision 2 --reads 128 --window 301 --sites 2048 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path", 1),
            "bf16x3": ("--precision 1 --sites 4096 --steps 1 --warmup 0 --no-cpu-baseline --no-skip-pass --no-host-path", 1)}
     for name, (command, passes) in pmc.items():
@@ -154,23 +185,29 @@ def extras(tag, dst):
         csv_out = os.path.join(dst, "%s_%s_pmc_summary.csv" % (tag, name))
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), src, csv_out, "--command", command])
         rows = list(csv.DictReader(l for l in open(csv_out) if not l.startswith("#")))
-        if name == "train":
+        b = build_of(os.path.join(src, "FETCH_SIZE.json"))
+        if b.get("source_hash") != build_of(os.path.join(src, "WRITE_SIZE.json")).get("source_hash"):
+            raise SystemExit("the FETCH_SIZE and WRITE_SIZE passes of %s ran on different builds" % name)
+        ident = {"source_hash": b.get("source_hash"), "chunk_sites": b.get("chunk_sites")}
+        if name.startswith("train"):
+            sites = 10 if name == "train_b10" else 64
             total = sum(float(r["hbm_bytes"]) * int(r["dispatches"]) for r in rows if r["hbm_bytes"] != "nan") / passes
-            traffic["train_step"] = {"command": "bench.py " + command, "hbm_bytes_per_step": total,
+            traffic["train_step_b%d" % sites] = {"command": "bench.py " + command, "hbm_bytes_per_step": total,
+                                     "source_hash": ident["source_hash"],
                                      "note": "sum over every kernel of the step of (2 x FETCH_SIZE + WRITE_SIZE) per dispatch x dispatches, "
-                                             "/ %d steps; 64 sites x 100 reads x 201 bp" % passes}
+                                             "/ %d steps; %d sites x 100 reads x 201 bp" % (passes, sites)}
         elif name == "bf16x3":
             for r in rows:
                 if "segmentx_kernel" in r["kernel"]:
                     traffic["segmentx_kernel_bytes_per_launch"] = {
-                        "command": "bench.py " + command, "total": float(r["hbm_bytes"]), "dispatches": int(r["dispatches"]),
+                        "command": "bench.py " + command, "total": float(r["hbm_bytes"]), "dispatches": int(r["dispatches"]), **ident,
                         "note": "chunk of 2048 sites x 64 reads x 201 bp, averaged over the two launches of a chunk (layers 1-2, layers 3-7)"}
         else:
             for r in rows:
                 if "segmentp_kernel" in r["kernel"]:
                     traffic["segmentp_kernel_bytes_per_launch"] = {
-                        "command": "bench.py " + command, "total": float(r["hbm_bytes"]), "dispatches": int(r["dispatches"]),
-                        "note": "chunk of 512 sites x 128 reads x 301 bp, averaged over the two launches of a chunk (layers 1-2, layers 3-7)"}
+                        "command": "bench.py " + command, "total": float(r["hbm_bytes"]), "dispatches": int(r["dispatches"]), **ident,
+                        "note": "chunk of %s sites x 128 reads x 301 bp, averaged over the two launches of a chunk (layers 1-2, layers 3-7)" % ident["chunk_sites"]}
     json.dump(traffic, open(tpath, "w"), indent=1)
     lines = os.path.join(go, "lines_" + tag)
     for f in sorted(glob.glob(os.path.join(lines, "*.json"))):
@@ -178,12 +215,15 @@ def extras(tag, dst):
         if ls:
             rec = json.loads(ls[-1])
             base = os.path.basename(f)[:-5]
-            if base == "train" and "train_step" in traffic:
-                rec["roofline"]["traffic"] = int(traffic["train_step"]["hbm_bytes_per_step"])
-            if base == "bf16x3" and "segmentx_kernel_bytes_per_launch" in traffic:
-                rec["roofline"]["traffic"] = int(traffic["segmentx_kernel_bytes_per_launch"]["total"])
-            if base == "bf16_128x301" and "segmentp_kernel_bytes_per_launch" in traffic:
-                rec["roofline"]["traffic"] = int(traffic["segmentp_kernel_bytes_per_launch"]["total"])
+            # (a line printed before its counters existed carries the traffic measured for the same command on the same build)
+            def same(sec):
+                t, b = traffic.get(sec), rec.get("build", {})
+                return bool(t) and t.get("source_hash") == b.get("source_hash") and t.get("chunk_sites") in (None, b.get("chunk_sites"))
+            for b_, sec, key in (("train", "train_step_b64", "hbm_bytes_per_step"), ("train_b10", "train_step_b10", "hbm_bytes_per_step"),
+                                 ("bf16x3", "segmentx_kernel_bytes_per_launch", "total"), ("bf16_128x301", "segmentp_kernel_bytes_per_launch", "total")):
+                if base == b_ and same(sec):
+                    rec["roofline"]["traffic"] = int(traffic[sec][key])
+                    rec["roofline"]["traffic_stale"] = False
             with open(os.path.join(dst, "%s_bench_line_%s.json" % (tag, base)), "w") as out:
                 out.write(json.dumps(rec) + "\n")
     for f in sorted(glob.glob(os.path.join(lines, "*.txt"))):
