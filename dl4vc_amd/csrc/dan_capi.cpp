@@ -62,6 +62,8 @@ struct dan_handle {
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
+    float* d_y2 = nullptr;                   // fp32 windows above MPOS columns (two units per read): the segments' y alternates between d_y and d_y2
+    bool split = false;
     int* d_rowsrc = nullptr;                 // empty-row map of the current chunk (skip_empty_rows)
     int *d_work = nullptr, *d_work_count = nullptr;   // ... and the list of rows to compute
     int n_cus = 0;
@@ -274,6 +276,13 @@ int prof_collect(dan_handle* h, KernelStat& st) {
     return 0;
 }
 
+// receptive-field radius of layers [l_begin, l_end) (0-based): the sum of their dilations (3 taps each; model.py:214-231)
+int segment_halo(const dan_config& c, int l_begin, int l_end) {
+    int halo = 0;
+    for (int l = l_begin; l < l_end; ++l) halo += (l == 0) ? 1 : (l + 1 < c.layers ? c.dil_mid : c.dil_final);
+    return halo;
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,7 +304,8 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     if (c.reads < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "reads must be >= 1");
     if (c.precision < 0 || c.precision > 2)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "precision %d unknown (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)", c.precision);
-    const int max_len = c.precision == 2 ? P_LMAX : MPOS;
+    // precision 0 above MPOS columns: every read as two overlapping units (dan_kernels.h plan_units; checked per segment below)
+    const int max_len = c.precision == 1 ? MPOS : P_LMAX;
     if (c.length < 8 || c.length > max_len)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the LDS-resident path at precision %d (8..%d)", c.length, c.precision, max_len);
     if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD)
@@ -334,7 +344,8 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         // the feature matrix, FC workspaces and weights take their share of the rest)
         // (precision 2 keeps y and h as bf16: half the bytes per site, twice the sites per chunk -- 1024 at 128 x 301)
         const double elem = c.precision == 2 ? 2.0 : 4.0;
-        const double per_site = (double)c.reads * c.length * (CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * elem;
+        const double y_copies = (c.precision == 0 && c.length > MPOS) ? 2.0 : 1.0;       // (two units per read: y out of place)
+        const double per_site = (double)c.reads * c.length * (y_copies * CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * elem;
         double budget = 48e9;
         size_t free_b = 0, total_b = 0;
         // (hipMemGetInfo reports on the CURRENT device: switch for the question, then back -- dan_create leaves the calling
@@ -363,6 +374,21 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     for (int l1 = 1; l1 <= c.layers; ++l1)
         if (l1 == c.layers || pool_after(c, l1)) { h->seg_begin.push_back(b); h->seg_end.push_back(l1); b = l1; }
     h->n_segments = (int)h->seg_begin.size();
+    if (c.precision == 0 && c.length > MPOS) {
+        // every segment's two units must fit the 208-row image: half the window + the segment's receptive-field radius
+        for (int sg = 0; sg < h->n_segments; ++sg) {
+            SegmentArgs probe{};
+            const int halo = segment_halo(c, h->seg_begin[sg], h->seg_end[sg]);
+            if (!plan_units(probe, c.length, halo)) {
+                const int rc = fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported at precision 0 with these dilations: layers %d..%d reach %d "
+                                    "columns sideways, half the window plus that exceeds the %d-column LDS image", c.length,
+                                    h->seg_begin[sg] + 1, h->seg_end[sg], halo, MPOS);
+                delete h;
+                return rc;
+            }
+        }
+        h->split = true;
+    }
     *out = h;
     return DAN_OK;
 }
@@ -600,6 +626,7 @@ int dan_finalize(dan_t* h) {
     const size_t read_floats = (size_t)L * CPAD;
     const size_t act_div = h->use_p ? 2 : 1;                 // (bf16 y / h: half a float per element)
     if ((rc = dev_alloc(h, &h->d_y, (size_t)h->chunk * R * read_floats / act_div))) return rc;
+    if (h->split && (rc = dev_alloc(h, &h->d_y2, (size_t)h->chunk * R * read_floats))) return rc;
     if ((rc = dev_alloc(h, &h->d_pool, (size_t)h->chunk * read_floats))) return rc;
     if (conv_pool && h->n_segments > 1) {
         if ((rc = dev_alloc(h, &h->d_cp, (size_t)h->chunk * read_floats))) return rc;
@@ -670,6 +697,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 launch_row_map(reads + g0 * rl, qual + g0 * rl, strand + g0 * rl, h->d_rowsrc, h->d_work, h->d_work_count, ns, R, L, s);
                 rcm = prof_end(h, "row_map", s, &evm); if (rcm) return rcm;
             }
+            float* y_seg = h->d_y;                           // where the segment just launched left its output
             for (int sg = 0; sg < h->n_segments; ++sg) {
                 SegmentArgs a{};
                 a.wl = h->d_wl;
@@ -680,7 +708,13 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                 a.reads = reads + g0 * rl; a.qual = qual + g0 * rl; a.strand = strand + g0 * rl;
                 a.ref = ref + g0 * L; a.ref_mask = ref_mask + g0 * L; a.var_mask = var_mask + g0 * L;
                 a.emb = h->d_emb; a.pe = h->d_pe;
-                a.y = h->d_y;
+                // one unit per read and y in place -- or, above MPOS columns at precision 0, two units per read and y alternating
+                // between two buffers (a unit reads the other unit's columns of the input while that one stores its output)
+                float* const y_in = y_seg;                   // the previous segment's output
+                if (h->split) y_seg = (y_seg == h->d_y) ? h->d_y2 : h->d_y;
+                a.y = y_in; a.y_out = y_seg;
+                if (c.precision == 0 && !plan_units(a, L, segment_halo(c, a.l_begin, a.l_end)))
+                    return fail(h, DAN_ERR_STATE, "unit plan failed for segment %d", sg);
                 a.pool = sg > 0 ? h->d_pool : nullptr;
                 a.h = h->d_h; a.h_layer_stride = h_layer_stride;
                 const bool tap_here = h->tap_layer >= 0 &&
@@ -722,7 +756,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
                         const int ln = h->seg_begin[sg + 1];                      // 0-based layer behind the pool: its dilation
                         launch_conv_pool(h->d_pool, h->d_wpool + (size_t)(sg + 1) * CPAD * 3 * CPAD, h->d_zero, h->d_cols, h->d_cp, ns, L,
                                          ln + 1 < c.layers ? c.dil_mid : c.dil_final, s);
-                    } else launch_read_mean(h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                    } else launch_read_mean(y_seg, h->d_pool, ns, R, L, h->d_rowsrc, s);
                     rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
                     HIPCHK(h, hipGetLastError());            // a refused launch must not let garbage flow on to the FC
                 }
@@ -732,7 +766,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
             int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
             if (h->use_x) launch_final_poolx((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             else if (h->use_p) launch_final_pool16((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
-            else launch_final_pool(h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
+            else launch_final_pool(y_seg, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             rc = prof_end(h, "pool", s, &ev); if (rc) return rc;
             HIPCHK(h, hipGetLastError());
             if (H > 0) {

@@ -85,9 +85,10 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MTW][NT], const float* xs, 
 // -- 4/4/3/3/3/3/3/3 units, i.e. 7/7/6/6 per SIMD.  All eight weight fragments are preloaded by the caller (wf).
 // NW = participating waves: all 8 (standalone stage), or only the 4 OLDER waves (0..3, one per SIMD) when the GEMM is
 // deferred into the next layer's conv stage (see the Winograd layer body).
-template <int NW>
+// RANGE: only positions p_lo <= p < L are stored (a unit of a split read stores its own columns; dan_kernels.hip SPLIT).
+template <int NW, bool RANGE = false>
 __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
-                                           int wave, int lane) {
+                                           int wave, int lane, int p_lo = 0) {
     constexpr int PSTEP = NW / 2;                         // position-tile stride of one wave
     constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
     // everything below is recomputed per call from an opaque copy of the lane index: hoisted out of the layer loop, the
@@ -126,7 +127,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
 #pragma unroll
     for (int i = 0; i < NBT; ++i) {
         const int pt = p0 + PSTEP * i, p = pt * 16 + pos;
-        if (pt < MT && p < L) {
+        if (pt < MT && p < L && (!RANGE || p >= p_lo)) {
             v4f v = acc[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
@@ -135,8 +136,9 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
     }
 }
 
-__device__ __forceinline__ void copy_out(const float* xs, float* dst, int L, int tid) {
-    for (int i = tid; i < L * (CPAD / 4); i += SEG_THREADS) {
+// image rows [lo, hi) -> dst rows [lo, hi)   (lo = 0, hi = L: the whole read)
+__device__ __forceinline__ void copy_out(const float* xs, float* dst, int lo, int hi, int tid) {
+    for (int i = lo * (CPAD / 4) + tid; i < hi * (CPAD / 4); i += SEG_THREADS) {
         const int p = i >> 5, c4 = i & 31;
         ((v4f*)dst)[i] = *(const v4f*)(xs + (HALO + p) * LDS_S + c4 * 4);
     }
@@ -158,29 +160,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // a - b as two v_pk_fma_f32 (b * m1 + a with m1 = -1.0 in a register the compiler cannot see through: hipcc turns a
 // v2f32 fsub, or an fma by a literal -1, into two scalar v_sub_f32; every VALU instruction costs the SIMD 3-5 cycles of
 // MFMA issue -- tools/ubench/mfma_valu.hip -- so the packed form halves the price of the input transform)
-#ifdef DAN_WINO_UNPACKED
-// A/B build (VERDICT r3 item 4a, MI355X_MICROARCH.md "packed f32 VALU beside MFMAs is an anti-lever"): the same transform as
-// sixteen one-float instructions per tile.  As inline assembly, or hipcc's SLP pass packs them again.  Measured: see DESIGN.md.
-__device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f) {
-    v4f r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { float t; asm("v_sub_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(b[i])); r[i] = t; }
-    return r;
-}
-__device__ __forceinline__ v4f pk_add(v4f a, v4f b) {
-    v4f r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { float t; asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(b[i])); r[i] = t; }
-    return r;
-}
-#else
+// (round 4 measured the one-float form of the same transform, sixteen v_sub/v_add per tile: 71.85 ms per launch against 71.02 --
+// HISTORY.md, round 4, item 4a; the losing variant is not kept in the source)
 __device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
     const v2f lo = __builtin_elementwise_fma((v2f){b[0], b[1]}, m1, (v2f){a[0], a[1]});
     const v2f hi = __builtin_elementwise_fma((v2f){b[2], b[3]}, m1, (v2f){a[2], a[3]});
     return (v4f){lo[0], lo[1], hi[0], hi[1]};
 }
 __device__ __forceinline__ v4f pk_add(v4f a, v4f b) { return a + b; }
-#endif
 __device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
     v4f a_nxt[4];
 #pragma unroll

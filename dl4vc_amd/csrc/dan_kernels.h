@@ -15,7 +15,7 @@ constexpr int SEG_THREADS = NWAVE * 64;
 // matrix pipe ~7.4 cycles: tools/ubench/mfma_feed.hip).
 constexpr int NT = 2;
 constexpr int MTW = 7;                  // position tiles per wave (the upper half uses MT - MTW = 6 of them)
-constexpr int MT = 13;                  // 16-position tiles per read         (L <= 208)
+constexpr int MT = 13;                  // 16-position tiles per LDS-resident unit: a read of <= 208 columns, or half of a longer one (SegmentArgs::units)
 constexpr int MPOS = MT * 16;           // 208
 constexpr int HALO = 4;                 // zero rows either side of the window (dilation <= 4)
 constexpr int LDS_S = 136;              // floats per LDS position row: 128 + 8 makes the ds_read_b128 B-fragment reads conflict-free
@@ -69,7 +69,35 @@ struct SegmentArgs {
     int xcd_rows;                // filled by launch_segment: rows per XCD slice (whole sites)
     const int* work;             // rows to compute (device list, see launch_row_map); read only when work_count is set
     const int* work_count;       // length of that list (device) or nullptr = every row
+    // ---- windows of 209..304 columns (units == 2; plan_units fills these): a read no longer fits the 208-row LDS image, so it
+    // is computed as TWO overlapping units, each an ordinary <= 208-column "read" of the kernel: unit u covers window columns
+    // [u_off, u_off + u_len) and STORES (y, h, tap) only its own columns [own_lo, own_hi) (unit-relative).  The overlap is the
+    // segment's receptive-field radius (the sum of its layers' dilations): the zero padding the kernel applies at a unit's inner
+    // cut is wrong there and leaks one dilation further per layer, never into an owned column.  L is then unused; Lw = the
+    // window = the position stride of reads / ref / pe / y / pool / h / tap.  y_out != y: the other unit reads its overlap from
+    // y while this one stores (units == 1: Lw == L, y_out == y, in place as ever).
+    int units, Lw;
+    int u_off[2], u_len[2], own_lo[2], own_hi[2];
+    float* y_out;
 };
+
+// Windows above MPOS columns: two units per read (see SegmentArgs).  halo = the segment's receptive-field radius.  Returns false
+// when a unit would not fit (window > 2 (MPOS - halo)).  For Lw <= MPOS: one unit, the whole window.
+inline bool plan_units(SegmentArgs& a, int Lw, int halo) {
+    a.Lw = Lw;
+    if (Lw <= MPOS) {
+        a.units = 1; a.L = Lw;
+        a.u_off[0] = 0; a.u_len[0] = Lw; a.own_lo[0] = 0; a.own_hi[0] = Lw;
+        a.u_off[1] = 0; a.u_len[1] = 0; a.own_lo[1] = 0; a.own_hi[1] = 0;
+        return true;
+    }
+    const int mid = (Lw + 1) / 2;                                 // unit 0 owns [0, mid), unit 1 owns [mid, Lw)
+    if (mid + halo > MPOS || Lw - mid + halo > MPOS) return false;
+    a.units = 2; a.L = 0;
+    a.u_off[0] = 0; a.u_len[0] = mid + halo; a.own_lo[0] = 0; a.own_hi[0] = mid;
+    a.u_off[1] = mid - halo; a.u_len[1] = Lw - (mid - halo); a.own_lo[1] = halo; a.own_hi[1] = a.u_len[1];
+    return true;
+}
 
 // max_wgs: workgroups to launch (one per CU: they are persistent and walk the rows with the grid's stride); 0 = one per row
 void launch_segment(const SegmentArgs& a, int n_sites, int max_wgs, hipStream_t s);

@@ -84,7 +84,11 @@ __device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xro
 // a workgroup per row only to have a quarter of them exit costs the command processor ~0.26 us each, serialised.  The row
 // loop costs registers (what is live across rows), so that form re-reads its arguments per row and does without the
 // cross-layer weight prefetch; it is ~1 % slower per computed row.
-template <bool WINO, bool PERSIST>
+// SPLIT = true: windows of 209..304 columns, every read as two overlapping units (SegmentArgs::units == 2, plan_units): a work
+// item is (row, unit), `L` below is the UNIT's length and every position-indexed pointer is offset to the unit's first column;
+// what differs from the one-unit form is addressing (window stride Lw), the allele-agreement predicates (taken over the whole
+// window, not the unit) and the stores (own columns only, y out of place).  SPLIT = false compiles to the code it always was.
+template <bool WINO, bool PERSIST, bool SPLIT>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a_by_value) {
     // one allocation, so that the layout the Winograd tiles past the window rely on (constants right after the activation
     // rows) is explicit
@@ -94,11 +98,12 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(Segment
     typedef const __attribute__((address_space(4))) SegmentArgs* kernarg_ptr;
     // (the row body sits at function scope with an explicit back edge: wrapped in a lambda, or in a for loop left by a
     // compile-time break, the same code costs the non-persistent form 56 spilled registers)
-    const int n_work = a_by_value.work_count ? *a_by_value.work_count : a_by_value.n_rows;
+    constexpr int UNITS = SPLIT ? 2 : 1;
+    const int n_work = (a_by_value.work_count ? *a_by_value.work_count : a_by_value.n_rows) * UNITS;
     // XCD-aware order: workgroups b and b + 8 share an XCD (round-robin dealing), so the rows are cut into 8 contiguous
     // slices of `per` rows and workgroup b takes row (b % 8) * per + b / 8 (+ a multiple of the grid's eighth when
     // persistent): the 64 reads of a site, which all read that site's pool image and the same weights, stay in one L2.
-    const int per = a_by_value.work_count ? (n_work + 7) >> 3 : a_by_value.xcd_rows;
+    const int per = a_by_value.work_count ? (n_work + 7) >> 3 : a_by_value.xcd_rows * UNITS;
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;                                // position inside the XCD's slice
     int wk = xcd * per + j;
@@ -112,17 +117,25 @@ next_row:                                                   // (PERSIST only: ba
     if (PERSIST) asm volatile("" : "+s"(ap));
     auto args = [&]() -> decltype(auto) { if constexpr (PERSIST) return (*ap); else return (a_by_value); };
     const auto& a = args();
-    const int L = a.L;
+    // (SPLIT) the unit of this work item: all wave-uniform
+    [[maybe_unused]] const int unit = wk & 1;
+    const int L = SPLIT ? (unit ? a.u_len[1] : a.u_len[0]) : a.L;
+    const int Lw = SPLIT ? a.Lw : L;                             // position stride of the tensors
+    const int u_off = SPLIT ? (unit ? a.u_off[1] : a.u_off[0]) : 0;
+    [[maybe_unused]] const int own_lo = SPLIT ? (unit ? a.own_lo[1] : a.own_lo[0]) : 0;
+    [[maybe_unused]] const int own_hi = SPLIT ? (unit ? a.own_hi[1] : a.own_hi[0]) : L;
     [[maybe_unused]] const int stamp_row = wk;
     int tid = threadIdx.x;
     if (PERSIST) asm volatile("" : "+v"(tid));              // per-row: nothing derived from the thread index is hoisted out of
     const int lane = tid & 63;                              // the row loop (it would live through every GEMM and spill)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row_index = __builtin_amdgcn_readfirstlane(a.work_count ? a.work[wk] : wk);     // uniform: everything derived stays scalar
+    const int wrow = SPLIT ? wk >> 1 : wk;
+    const int row_index = __builtin_amdgcn_readfirstlane(a.work_count ? a.work[wrow] : wrow);     // uniform: everything derived stays scalar
     const int site = (int)((unsigned)row_index / (unsigned)a.R);
     const int r = row_index - site * a.R;
     const size_t read_idx = (size_t)site * a.R + r;
-    float* yrow = a.y + read_idx * (size_t)L * CPAD;
+    float* yrow = a.y + (read_idx * (size_t)Lw + u_off) * CPAD;                   // this unit's first column of the segment's input
+    float* yout = SPLIT ? a.y_out + (read_idx * (size_t)Lw + u_off) * CPAD : yrow;  // ... and of its output (in place unless SPLIT)
     const int pos = lane & 15, kk = lane >> 4;
     const int cq = wave & 3, ph = wave >> 2;                  // channel quarter, position half
     const int m_base = ph * MTW, cnt = ph ? MT - MTW : MTW;     // this wave's position tiles [m_base, m_base + cnt)
@@ -167,7 +180,7 @@ next_row:                                                   // (PERSIST only: ba
         __syncthreads();
         // ---- encode (dl4vc/model.py:450-627): canonical 48-channel order
         //      [read emb+pe (20) | ref emb+pe (20) | q*0.01 | strand*0.5 | refmatch | varmatch | lenmask | 0 0 0]
-        const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
+        const size_t rbase = read_idx * (size_t)Lw + u_off, sbase = (size_t)site * Lw + u_off;
         const int p = tid;
         const bool in = p < L;
         int tok = 0, q = 0, st = 0, rf = 0, rm = 0, vm = 0;
@@ -175,14 +188,20 @@ next_row:                                                   // (PERSIST only: ba
             tok = a.reads[rbase + p]; q = a.qual[rbase + p]; st = a.strand[rbase + p];
             rf = a.ref[sbase + p]; rm = a.ref_mask[sbase + p]; vm = a.var_mask[sbase + p];
         }
-        // a read agrees with an allele iff it equals the mask wherever the mask is non-zero (model.py:592-593)
-        const int agree_ref = __syncthreads_and((rm == 0) || (tok == rm));
-        const int agree_var = __syncthreads_and((vm == 0) || (tok == vm));
+        // a read agrees with an allele iff it equals the mask wherever the mask is non-zero (model.py:592-593) -- over the WHOLE
+        // window: a unit of a split read looks at the columns of the other unit too (Lw <= 304 < SEG_THREADS)
+        int tok_w = tok, rm_w = rm, vm_w = vm;
+        if constexpr (SPLIT) {
+            tok_w = rm_w = vm_w = 0;
+            if (tid < Lw) { tok_w = a.reads[rbase - u_off + tid]; rm_w = a.ref_mask[sbase - u_off + tid]; vm_w = a.var_mask[sbase - u_off + tid]; }
+        }
+        const int agree_ref = __syncthreads_and((rm_w == 0) || (tok_w == rm_w));
+        const int agree_var = __syncthreads_and((vm_w == 0) || (tok_w == vm_w));
         if (in) {
             float* row = xs + (HALO + p) * LDS_S;
             const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
             const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
-            const float* pp = a.pe + p * EMBED;
+            const float* pp = a.pe + (u_off + p) * EMBED;
 #pragma unroll
             for (int e = 0; e < EMBED; ++e) {
                 const float pv = pp[e];
@@ -198,7 +217,7 @@ next_row:                                                   // (PERSIST only: ba
     } else {
         // ---- resume from the previous segment's output, adding the broadcast read-mean (model.py:734-742)
         const v4f* src = (const v4f*)yrow;
-        const v4f* pl = a.pool ? (const v4f*)(a.pool + (size_t)site * L * CPAD) : nullptr;
+        const v4f* pl = a.pool ? (const v4f*)(a.pool + ((size_t)site * Lw + u_off) * CPAD) : nullptr;
         // a single CU streams at (bytes in flight) / latency: put the whole read (and the pool image) in flight
         // at once -- 26 + 26 sixteen-byte loads per lane -- instead of a few loads per round trip
         const int n4 = L * (CPAD / 4);
@@ -236,7 +255,7 @@ next_row:                                                   // (PERSIST only: ba
     }
     __syncthreads();
     STAMP(1);
-    if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, tid);
+    if (a.tap && a.tap_layer == 0 && a.l_begin == 0) copy_out(xs, a.tap + (read_idx * (size_t)Lw + u_off) * CPAD, own_lo, own_hi, tid);
 
     // per-layer prologue/tail shared by both forms
     v4f wbot[KGC];
@@ -247,7 +266,7 @@ next_row:                                                   // (PERSIST only: ba
         if (a.tap && a.tap_layer == l + 1) {                // (diagnostic path: its addresses must not be hoisted into registers)
             int t = tid;
             asm volatile("" : "+v"(t));
-            copy_out(xs, a.tap + read_idx * (size_t)L * CPAD, L, t);
+            copy_out(xs, a.tap + (read_idx * (size_t)Lw + u_off) * CPAD, own_lo, own_hi, t);
         }
         if (WINO && CARRY && late_prefetch && l + 1 < a.l_end) first_frags(l + 1, pn0, pn1, pn2, pn3);   // (direct first layer of the Winograd form)
         // WINO instantiation, not the segment's last layer: the bottleneck GEMM of this layer is deferred into the next
@@ -255,8 +274,8 @@ next_row:                                                   // (PERSIST only: ba
         // each SIMD is still in its conv GEMM (the arbiter serves the older wave first, so it finishes the conv early and
         // would only wait at the barrier)
         if (a.has_hw && !(WINO && l + 1 < a.l_end))
-            bottleneck<NWAVE>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L,
-                              wave, lane);
+            bottleneck<NWAVE, SPLIT>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + (read_idx * (size_t)Lw + u_off) * HPAD,
+                                     own_hi, wave, lane, own_lo);
         STAMP(sb + 7);
         if (CARRY) { pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3; }
     };
@@ -444,8 +463,8 @@ next_row:                                                   // (PERSIST only: ba
             gv4f_ptr w_bp = (gv4f_ptr)(wblk - LAYER_STRIDE + WBOT_OFF) + lane;
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bp[(g * 2 + (wave & 1)) * 64];
-            bottleneck<NWAVE / 2>(xs, wbot, lc - CST_FLOATS + CST_BBOT,
-                                  a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+            bottleneck<NWAVE / 2, SPLIT>(xs, wbot, lc - CST_FLOATS + CST_BBOT,
+                                         a.h + (size_t)(l - 1) * a.h_layer_stride + (read_idx * (size_t)Lw + u_off) * HPAD, own_hi, wave, lane, own_lo);
         }
         const bool bot_here = a.has_hw && !(l + 1 < a.l_end);
         if (bot_here && !residual) {
@@ -509,7 +528,7 @@ next_row:                                                   // (PERSIST only: ba
         for (int l = a.l_begin; l < a.l_end; ++l) direct_layer(l);
     }
     STAMP(62);
-    copy_out(xs, yrow, L, tid);
+    copy_out(xs, yout, own_lo, own_hi, tid);
     STAMP(63);
     }
     if constexpr (PERSIST) {
@@ -524,14 +543,25 @@ void launch_segment(const SegmentArgs& a0, int n_sites, int max_wgs, hipStream_t
     SegmentArgs a = a0;
     a.n_rows = n_sites * a.R;
     a.xcd_rows = ((n_sites + 7) / 8) * a.R;                 // whole sites per XCD slice
-    const bool persist = a.work_count != nullptr && max_wgs >= 8 && max_wgs < a.n_rows;
-    const dim3 grid((unsigned)(persist ? (max_wgs & ~7) : 8 * a.xcd_rows)), blk(SEG_THREADS);
-    if (persist) {
-        if (a.wino) hipLaunchKernelGGL((segment_kernel<true, true>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((segment_kernel<false, true>), grid, blk, 0, s, a);
+    const bool split = a.units == 2;
+    if (!split) { a.units = 1; a.Lw = a.L; a.y_out = a.y; }   // (callers that never heard of units: one unit, the whole window, in place)
+    const int units = split ? 2 : 1;
+    const bool persist = a.work_count != nullptr && max_wgs >= 8 && max_wgs < a.n_rows * units;
+    const dim3 grid((unsigned)(persist ? (max_wgs & ~7) : 8 * a.xcd_rows * units)), blk(SEG_THREADS);
+    if (split) {
+        if (persist) {
+            if (a.wino) hipLaunchKernelGGL((segment_kernel<true, true, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((segment_kernel<false, true, true>), grid, blk, 0, s, a);
+        } else {
+            if (a.wino) hipLaunchKernelGGL((segment_kernel<true, false, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((segment_kernel<false, false, true>), grid, blk, 0, s, a);
+        }
+    } else if (persist) {
+        if (a.wino) hipLaunchKernelGGL((segment_kernel<true, true, false>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((segment_kernel<false, true, false>), grid, blk, 0, s, a);
     } else {
-        if (a.wino) hipLaunchKernelGGL((segment_kernel<true, false>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((segment_kernel<false, false>), grid, blk, 0, s, a);
+        if (a.wino) hipLaunchKernelGGL((segment_kernel<true, false, false>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((segment_kernel<false, false, false>), grid, blk, 0, s, a);
     }
 }
 

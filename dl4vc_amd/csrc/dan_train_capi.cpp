@@ -966,6 +966,7 @@ int64_t dan_train_get_tensor(dan_trainer_t* t, const char* name, float* dst, int
         else if (nm[4] == 'h' && t->d_h) { src = t->d_h + (size_t)l * rows * c.length * HPAD; n = rows * c.length * HPAD; }
     } else if (nm == "feature") { src = t->d_feat; n = (int64_t)B * t->F_stride; }
     else if (nm == "dfeature") { src = t->d_dfeat; n = (int64_t)B * t->F_stride; }
+    else if (nm == "du0") { src = t->d_du; n = rows * c.length * CPAD; }      // after a step: the gradient of the encoded input (canonical channel order)
     else if (nm == "logits") { src = t->d_logits; n = (int64_t)B * NHEAD; }
     else if (nm == "dlogits") { src = t->d_dlogits; n = (int64_t)B * NHEAD; }
     if (src) {

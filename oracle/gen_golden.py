@@ -322,6 +322,27 @@ def gen_bf16_fixtures(m):
         save_case(name, spec, sd, batch, keep)
 
 
+def gen_long_window_fixtures(m):
+    """Windows of 209..304 columns in fp32 (the reference takes any single_read_len, model.py:41,154-162; its pool kernels cover
+    the window through ceil_mode): the reference's own fp32 forward on (a) the inputs and weights of bf16_operands_l301 -- so the
+    301-column case is pinned in fp32 and in bf16 on the same data -- and (b) a wider network at the 304-column capacity with two
+    pool layers (three segments).  The fp32 HIP path computes such reads as two overlapping units (dan_kernels.h plan_units)."""
+    cases = {
+        "long_l301": (OracleSpec(reads=6, length=301, layers=7, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8)),
+                      synth.make_sites(4, reads=6, length=301, seed=801), 701),
+        "long_l304": (OracleSpec(reads=5, length=304, layers=7, c_init=48, c_final=32, bottleneck=8, fc_sizes=(16, 8), pool_layers=(2, 4)),
+                      synth.make_sites(3, reads=5, length=304, seed=802), 702),
+    }
+    for name, (spec, batch, seed) in cases.items():
+        sd = random_state_dict(spec, seed=seed)
+        out = run_reference(m, spec, sd, batch, taps=True)
+        check_oracle(spec, sd, batch, out, name)
+        keep = {k: v for k, v in out.items() if not k.startswith("conv")}
+        keep["conv2"] = out["conv2"][:2]
+        keep["conv7"] = out["conv7"][:2]
+        save_case(name, spec, sd, batch, keep)
+
+
 VCF_TABLE = [
     # (REF, ALT, window edits)   -- window edits: list of (col, token)
     ("A", "G", []),
@@ -516,11 +537,13 @@ def gen_cli_fixture():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     m, d, u = import_reference()
-    which = sys.argv[1:] or ["model", "bf16", "dataset", "vcf", "cli"]
+    which = sys.argv[1:] or ["model", "bf16", "long", "dataset", "vcf", "cli"]
     if "model" in which:
         gen_model_fixtures(m)
     if "bf16" in which:
         gen_bf16_fixtures(m)
+    if "long" in which:
+        gen_long_window_fixtures(m)
     if "dataset" in which:
         gen_dataset_fixtures(d, u)
     if "vcf" in which:

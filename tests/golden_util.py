@@ -21,6 +21,11 @@ def model_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "dan_*.npz")))
 
 
+def long_cases():
+    """Windows of 209..304 columns (oracle/gen_golden.py::gen_long_window_fixtures: the reference's fp32 forward)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "long_*.npz")))
+
+
 def input_tuple(inputs):
     return tuple(inputs[k] for k in ("reads", "qual", "strand", "ref", "ref_mask", "var_mask"))
 

@@ -83,6 +83,41 @@ def test_main_py_inference(tmp_path, gpus):
         assert line.split("\t")[1] == batch.vcfrec[i].split("\t")[1]
 
 
+def test_main_py_loads_a_legacy_format_checkpoint(tmp_path):
+    """`--modelload` with a file in the format the PUBLISHED checkpoint is in (docs/Step-by-step.md:14: written by torch 1.2 --
+    the legacy non-zip serialisation -- from a DataParallel model: module.-prefixed keys, BatchNorm counters, an Adam `optimizer`
+    entry, main.py:194-199): main.py scores with it, and the scored VCF is byte-identical to the run from the same weights saved
+    in today's zip format.  tests/test_checkpoint_formats.py checks the loader itself on CPU."""
+    import zipfile
+    from test_checkpoint_formats import reference_style_checkpoint
+    import torch
+    cfg = DanConfig(reads=100)
+    ck, sd = reference_style_checkpoint(cfg, seed=21)
+    batch = synth.make_sites(12, reads=100, seed=41)
+    hdf = str(tmp_path / "candidates.hdf")
+    hdf5io.write_candidates(hdf, hdf5io.records_from_sites(batch))
+    sample = str(tmp_path / "candidates.vcf")
+    open(sample, "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n")
+    texts = {}
+    for fmt in ("legacy", "zip"):
+        path = str(tmp_path / ("checkpoint_%s.pth.tar" % fmt))
+        torch.save(ck, path, _use_new_zipfile_serialization=(fmt == "zip"))
+        assert zipfile.is_zipfile(path) == (fmt == "zip")
+        out = str(tmp_path / ("%s_test.vcf" % fmt))
+        cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--test_file", hdf, "--modelload", path, "--sample_vcf", sample,
+               "--save_vcf_records", "--save_vcf_records_file", out] + MODEL_FLAGS
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        texts[fmt] = open(str(tmp_path / ("epoch1_%s_test.vcf" % fmt))).read()
+    assert texts["legacy"] == texts["zip"]
+    body = texts["legacy"].splitlines()[2:]
+    assert len(body) == 12
+    want = dan_forward_oracle(sd, cfg, *batch.arrays())
+    for i, line in enumerate(body):
+        s = _scores(line)
+        assert abs(s[0] - want["bp"][i]) < 1e-4 and np.abs(s[1:] - want["vt_prob"][i]).max() < 1e-4, (i, s)
+
+
 def _bench_launch(how, bench_args):
     """`driver`: exactly as the driver launches N > 1 (torch.distributed.run, one rank per GPU); `self`: plain
     `python bench.py --gpus 2` with no WORLD_SIZE -- bench.py then starts the ranks itself (resolve_ranks)."""

@@ -31,6 +31,25 @@ def _close(got, ref, tol, what):
     return err / scale
 
 
+# (case, head) -> bar where the split-bf16 chain needs more than 1e-4 of the head's magnitude.  Measured in round 5 over the 11
+# cases x 6 heads (profiles/r05_bf16x3_head_errors.json): 65 of 66 at or below 6.7e-5; the one exception is the 10-way base head of
+# the two-pool-layer case at 1.016e-4 -- that structure sends the read mean through conv(pool) twice, each an fp32 GEMM seeding
+# split-bf16 accumulators; every head of that 8-channel network is below 1 in magnitude, so the bar is an absolute 1e-4 there, and
+# `vb` (ten outputs, max 0.80) carries the largest absolute error of the six (the others: 7e-6 .. 5.3e-5)
+HEAD_BARS = {("dan_var_pool24", "vb"): 1.2e-4}
+
+
+def _record_head_errors(case, errs):
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "bf16x3_head_errors.json")
+    rec = json.load(open(path)) if os.path.isfile(path) else {}
+    rec[case] = errs
+    json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
+
+
 @pytest.mark.parametrize("case", model_cases())
 def test_bf16x3_golden_outputs_and_taps(case):
     """Every reference-generated case (the production flags and the ten structural variants): scores within 1e-4 absolute, logits,
@@ -43,10 +62,16 @@ def test_bf16x3_golden_outputs_and_taps(case):
     for k in ("vt_prob", "bp"):
         assert np.abs(got[k] - out[k]).max() < 1e-4, (case, k, float(np.abs(got[k] - out[k]).max()))
     errs = {k: float(np.abs(got[k] - out[k]).max()) for k in ("vt_prob", "bp")}
-    # the six head outputs are the END of the chain (two operand pieces of 8 bits each: 2^-17 per operand and layer): held to
-    # 2e-4 of their magnitude (observed <= 1.2e-4), the intermediate tensors below to the fp32 path's 1e-4
+    # the six head outputs are the END of the chain (two operand pieces of 8 bits each: 2^-17 per operand and layer).  They are held
+    # to the fp32 path's 1e-4 of their magnitude like every other tensor, EXCEPT the (case, head) pairs of HEAD_BARS below, each
+    # with its measured error: all of them are collected (and written to gpurun_out/bf16x3_head_errors.json) before any is judged
     for k in ("bin_logits", "vt_logits", "af", "cov", "vb", "vr"):
-        errs[k] = _close(got[k], out[k], 2e-4, "%s:%s" % (case, k))
+        scale = max(1.0, float(np.abs(out[k]).max()))
+        errs[k] = float(np.abs(got[k].astype(np.float64) - out[k]).max()) / scale
+    _record_head_errors(case, errs)
+    for k in ("bin_logits", "vt_logits", "af", "cov", "vb", "vr"):
+        bar = HEAD_BARS.get((case, k), 1e-4)
+        assert errs[k] <= bar, "%s:%s: %.3g of the tensor's magnitude > %.3g" % (case, k, errs[k], bar)
     F, Fs = net.handle.query("feature_width"), net.handle.query("feature_stride")
     B = inp["reads"].shape[0]
     if "feature" in out:
@@ -141,12 +166,7 @@ def test_bf16_config5_stress_shape():
     assert np.abs(got["vt_prob"] - want["vt_prob"]).max() < 0.05
 
 
-def test_fp32_rejects_long_window_but_bf16_accepts():
-    with pytest.raises(RuntimeError, match="length"):
-        DanNet(DanConfig(reads=8, length=301))
-    with pytest.raises(RuntimeError, match="length"):
-        DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16X3))
-    DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16)).close()
+# (which window lengths each precision takes: tests/test_hip_long_window.py::test_window_limits_per_precision)
 
 
 @pytest.mark.parametrize("form", [0, 1])

@@ -2,14 +2,14 @@
 import numpy as np
 import pytest
 
-from golden_util import load_case, model_cases, input_tuple
+from golden_util import load_case, model_cases, long_cases, input_tuple
 from oracle.dan_oracle import dan_forward_oracle, OracleSpec, spec_from
 
 # fp32 CPU restatement vs fp32 CPU reference: identical op sequence, so the bar is roundoff
 ATOL = 2e-5
 
 
-@pytest.mark.parametrize("case", model_cases())
+@pytest.mark.parametrize("case", model_cases() + long_cases())
 def test_oracle_matches_reference_outputs(case):
     spec, w, inp, out = load_case(case)
     mine = dan_forward_oracle(w, spec, *input_tuple(inp), taps=True)
@@ -21,6 +21,20 @@ def test_oracle_matches_reference_outputs(case):
         assert got.shape == ref.shape, k
         scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
         np.testing.assert_allclose(got, ref, rtol=0, atol=ATOL * scale, err_msg="%s:%s" % (case, k))
+
+
+def test_the_301_column_case_is_pinned_in_fp32_and_in_bf16_on_the_same_data():
+    """long_l301 (the reference's fp32 forward) and bf16_operands_l301 (its forward with bf16-rounded GEMM operands) share inputs
+    and weights: the fp32 HIP path at 301 columns (two units per read) and the bf16 path are held to the same site data."""
+    assert set(long_cases()) >= {"long_l301", "long_l304"}
+    a, b = load_case("long_l301"), load_case("bf16_operands_l301")
+    assert a[0] == b[0] and a[0]["length"] == 301
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k]), k
+    assert float(np.abs(a[3]["vt_logits"] - b[3]["vt_logits"]).max()) > 1e-4     # ... and are different evaluations of it
+    assert load_case("long_l304")[0]["length"] == 304 and tuple(load_case("long_l304")[0]["pool_layers"]) == (2, 4)
 
 
 def test_small_case_covers_edge_sites():
