@@ -230,19 +230,29 @@ def bench_train(args):
     (o0, n0), (o1, n1) = tr.grad_buckets()
 
     sums_dev = "cuda" if backend == "nccl" else "cpu"
+    # what the exchange costs a step beyond the device step itself (host clock, this rank): the three-number all-reduce of the loss
+    # normalisers in front of it, and the wait from the end of the backward pass (dan_train_backward_end has synchronised) to the
+    # end of the last bucket's exchange -- bucket 0 travels under the conv layers' backward, so this is bucket 1 + what of bucket 0
+    # did not hide.  tools/scale_run.sh prints it per N.
+    ex_ms = {"normalisers": 0.0, "exposed": 0.0, "steps": 0}
 
     def step(i):
         if world > 1:
+            t_a = time.perf_counter()
             g = torch.tensor(base_class_weight_sums(tg), dtype=torch.float64, device=sums_dev)     # full-batch loss normalisers
             dist.all_reduce(g)
             g = g.cpu().numpy() / world
+            t_b = time.perf_counter()
             tr.set_global_batch(g[0], g[1], g[2])
             tr.backward_begin(planes, tg, seed=i)
             tr.wait_bucket(0)
             exchange.start(grad[o0:o0 + n0])                  # FC stack + heads: exchanged under the conv layers' backward
             out = tr.backward_end()
+            t_c = time.perf_counter()
             exchange.start(grad[o1:o1 + n1])
             exchange.finish()
+            t_d = time.perf_counter()
+            ex_ms["normalisers"] += (t_b - t_a) * 1e3; ex_ms["exposed"] += (t_d - t_c) * 1e3; ex_ms["steps"] += 1
         else:
             out = tr.backward(planes, tg, seed=i)
         tr.apply()
@@ -257,6 +267,7 @@ def bench_train(args):
     for i in range(args.warmup):
         step(i)
     fence()
+    ex_ms.update(normalisers=0.0, exposed=0.0, steps=0)
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
@@ -292,6 +303,12 @@ def bench_train(args):
                              "traffic": traffic, "traffic_stale": stale,
                              "kernel": "whole step (train_row_kernel + train_wgrad_kernel + train_point_kernel dominate; per-kernel "
                                        "durations and HBM bytes: profiles/rNN_train_kernel_stats.csv, rNN_train_pmc_summary.csv)"},
+                "exchange": None if world == 1 else {
+                    "form": "direct reduce-scatter + all-gather (all-to-all of 1/N chunks, rank-ordered shard sum)" if exchange.direct else "all-reduce",
+                    "backend": backend, "bucket_floats": [int(n0), int(n1)],
+                    "exposed_ms_per_step": round(ex_ms["exposed"] / max(ex_ms["steps"], 1), 3),
+                    "normalisers_ms_per_step": round(ex_ms["normalisers"] / max(ex_ms["steps"], 1), 3),
+                    "note": "rank 0's host clock: exposed = end of the backward pass to the end of the last bucket's exchange"},
                 "last_step": {k: round(float(last[k]), 6) for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr")}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle.dan_train_oracle import train_step_oracle, TrainHyper as OH

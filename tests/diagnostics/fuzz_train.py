@@ -18,8 +18,8 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 bad = flips = 0
 for seed in range(first, first + count):
     try:
-        worst = T.run_random_train_case(seed)
-        print("seed %d ok (worst gradient %s at %.2g of its max)" % (seed, worst[0], worst[1]), flush=True)
+        worst, branch = T.run_random_train_case(seed)
+        print("seed %d ok, %s branch (worst gradient %s at %.2g of its max)" % (seed, branch, worst[0], worst[1]), flush=True)
     except (AssertionError, RuntimeError, ValueError) as e:
         diffs = [d for d in decision_differences(seed) if d[1]] if isinstance(e, AssertionError) else []
         if diffs and all(rel < 1e-5 for _, _, rel in diffs) and "grad " in str(e):

@@ -565,22 +565,36 @@ def random_train_case(seed, length=None, reads=None, sites=None):
 
 
 def run_random_train_case(seed, **shape):
+    """One random structure against the float64 oracle, with the production-width test's two branches: the sweep of round 5
+    (tests/diagnostics/train_short_window_sweep.py, train_flip_check.py) showed that the sporadic misses of such cases -- at ANY
+    window length, 2e-2 of a tensor's max on a 16-channel network -- are ReLU inputs within 3e-6 of zero that the fp32 step
+    decides the other way (the fp32 torch oracle has its own, elsewhere): every differing decision must sit on a rounding
+    edge, and only a step without any is held to the tight bar."""
     import torch
     kw, cfg, sd, batch, hp, tg, masks = random_train_case(seed, **shape)
+    B = len(batch)
     ohp = T.TrainHyper(**{k: getattr(hp, k) for k in T.TrainHyper.__dataclass_fields__})
-    want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64)
+    want = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks, dtype=torch.float64, taps=True)
     w32 = T.train_step_oracle(sd, cfg, batch.arrays(), tg, ohp, dropout_masks=masks)
     tr = DanTrainer(cfg, hp, max_batch=8).load_state_dict(sd)
     out = tr.train_step(batch.arrays(), tg, dropout_masks=masks)
     tag = "seed %d %s dropout %s" % (seed, kw, hp.dropout)
     for k in ("loss", "bin", "vt", "af", "cov", "vb", "vr"):
         assert abs(out[k] - float(want[k])) <= 5e-5 * max(1.0, abs(float(want[k]))), (tag, k, out[k], float(want[k]))
-    assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * max(float(want["grad_norm"]), 1e-6), tag
+    differing = [d for d in decisions_differing(tr, want, cfg, B) if d[2]]
+    for kind, l, n, largest in differing:
+        assert largest <= DECISION_MARGIN[kind], "%s: %d %s decisions of layer %d differ from the float64 oracle's, one on an operand of %.3g" % (tag, n, kind, l, largest)
     grads = {k[5:]: v for k, v in want.items() if k.startswith("grad:")}
-    slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
-    worst = check_grads(tr, grads, tag, slack)
+    if not differing:
+        assert abs(out["grad_norm"] - float(want["grad_norm"])) <= 2e-4 * max(float(want["grad_norm"]), 1e-6), tag
+        slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
+        worst = check_grads(tr, grads, tag, slack)
+    else:
+        worst = check_grads(tr, grads, "%s, %d decisions on rounding edges" % (tag, sum(d[2] for d in differing)),
+                            {k: 0.5 * (5e-2 - GRAD_RTOL) for k in grads})
+    print("%s: %s; worst gradient %s at %.2g of its max" % (tag, "tight branch" if not differing else "edge branch %s" % (differing,), *worst))
     tr.close()
-    return worst
+    return worst, ("tight" if not differing else "edge")
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -592,13 +606,19 @@ def test_random_structures_train_step_against_float64_oracle(seed):
     run_random_train_case(seed)
 
 
-@pytest.mark.parametrize("seed,length,reads,sites", [(20, 64, 13, 6), (21, 40, 9, 8), (22, 100, 16, 7), (23, 8, 5, 3), (24, 127, 11, 6)])
+@pytest.mark.parametrize("seed,length,reads,sites", [(20, 65, 13, 6), (20, 40, 13, 6), (21, 64, 9, 8), (22, 100, 16, 7), (23, 8, 5, 3), (24, 127, 11, 6),
+                                                     (20, 64, 13, 6), (21, 40, 9, 8)])
 def test_short_windows_train_step_against_float64_oracle(seed, length, reads, sites):
     """Windows below 128 columns.  The half-read row kernel writes TWO statistics entries per read whatever the window length,
     which at L < 128 is more than one per 64-position tile: d_stats was once sized for max(reads, tiles) and every BatchNorm pass
     of such a shape wrote and read past its end (no fixture or random case had L < 112).  Rows x 2 exceeds the old
-    size in every case here; the gradients are held to the float64 oracle like the other random structures."""
-    run_random_train_case(seed, length=length, reads=reads, sites=sites)
+    size in every case here; the gradients are held to the float64 oracle like the other random structures.  The first six
+    cases take the TIGHT branch on the round-5 kernels (asserted: a regression that pushed them onto the loose bar would otherwise
+    pass unnoticed); the last two are the ones the first run of this test failed on -- two and five ReLU inputs within 1e-6 of
+    zero decided the other way -- kept as edge-branch cases."""
+    _, branch = run_random_train_case(seed, length=length, reads=reads, sites=sites)
+    if (seed, length) not in ((20, 64), (21, 40)):
+        assert branch == "tight", branch
 
 
 def test_data_parallel_average_equals_the_full_batch_gradient():
