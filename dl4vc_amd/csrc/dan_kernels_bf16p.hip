@@ -1,6 +1,6 @@
 // Plain-bf16 conv-stack segment kernel for gfx950, "ping-pong" form (dan_config.precision = 2; BASELINE config 5:
 // 128 reads x 301 bp).  dl4vc/model.py:728-778 for one read resident in LDS, as in the other families, but built around
-// what bounded those at 8x the fp32 matrix rate:
+// what bounded those at 8x the fp32 matrix rate (HISTORY.md section 4):
 //
 //   * v_mfma_f32_32x32x16_bf16, wave = (channel quarter q = wave & 3) x (position half = wave >> 2): a 1-KiB ds_read_b128 of
 //     activations feeds 16 k MACs, a quarter of the LDS bytes per MAC of the 16-channel-per-wave mapping (whose conv stage sat
@@ -970,7 +970,7 @@ void launch_segmentp(const SegmentPArgs& a0, int n_sites, int n_cus, hipStream_t
     const int need = ((a.slice_rows + 0) < 1 ? 1 : a.slice_rows) * 8;       // no more workgroups than rows per slice x 8
     if (wgs > need) wgs = need;
     // form 1: the sixteen-wave form (16x16x32 tiles, four waves per SIMD) -- an independently written second implementation held to
-    // the same layer-by-layer oracle tests; measured 7 % slower end to end (the chip clocks the denser form lower: DESIGN.md 11.1).
+    // the same layer-by-layer oracle tests; measured 7 % slower end to end (the chip clocks the denser form lower: HISTORY.md 11.1).
     // (Round 3 also carried a staggered form -- position halves one phase apart -- measured 12 % slower and deleted in round 4: a vector
     // instruction of the SIMD's other wave delays an MFMA walk by its full issue time, so an epilogue beside a GEMM costs what it costs
     // behind it, and that form paid 20 % of redundant tiles on top.)

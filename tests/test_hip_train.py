@@ -79,7 +79,7 @@ def test_train_step_matches_reference_training_loop(case):
 def test_winograd_form_of_the_training_convolutions_is_opt_in_and_passes_the_fixtures():
     """conv_algo 2 runs the dilation-2 forward convolutions and data gradients in Winograd F(2,3) form (the inference kernel's
     core).  Same fixtures, same 1e-4 bar; it is not the default because at production width its larger rounding noise flips
-    more ReLU masks than the direct form does."""
+    more ReLU masks than the direct form does (HISTORY.md section 10)."""
     import dataclasses
     spec, hyper, w, steps, *_ = load_train_case("train_small")
     cfg, hp, st = dataclasses.replace(cfg_from(spec), conv_algo=2), hyper_from(hyper), steps[0]
