@@ -568,9 +568,17 @@ int dan_finalize(dan_t* h) {
         if (H > 0 && (rc = dev_upload(h, &h->d_wc16, wc16_all))) return rc;
     }
     if (h->use_x) {
-        for (int l = 0; l < c.layers; ++l)
-            memcpy(wlx.data() + (size_t)l * WX_LAYER_BYTES + WX_CST_OFF, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF,
-                   CST_FLOATS * sizeof(float));
+        for (int l = 0; l < c.layers; ++l) {
+            float* cx = (float*)(wlx.data() + (size_t)l * WX_LAYER_BYTES + WX_CST_OFF);
+            memcpy(cx, wl.data() + (size_t)l * LAYER_STRIDE + CST_OFF, CST_FLOATS * sizeof(float));
+            // this family's epilogue computes relu(acc + b) * sc + sh as max(acc, -b) * sc + (sh + b * sc) (dan_kernels_bf16x.hip):
+            // the bias slot holds -b, the shift slot sh + b * sc (formed in double)
+            for (int ch = 0; ch < CPAD; ++ch) {
+                const double b = cx[CST_BIAS + ch];
+                cx[CST_SHIFT + ch] = (float)((double)cx[CST_SHIFT + ch] + b * (double)cx[CST_SCALE + ch]);
+                cx[CST_BIAS + ch] = (float)-b;
+            }
+        }
         if ((rc = dev_upload(h, &h->d_wlx, wlx))) return rc;
     }
     if (conv_pool && h->n_segments > 1) {

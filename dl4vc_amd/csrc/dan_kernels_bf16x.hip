@@ -62,12 +62,19 @@ __device__ __forceinline__ void lds8(float (&v)[8], const float* p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = t0[j]; v[4 + j] = t1[j]; }
 }
-// 8 fp32 -> hi = bf16(v) (ties to even), lo = bf16(v - hi)
+// 8 fp32 -> hi = bf16(v) (ties to even), lo = bf16(v - hi).  Written on PAIRS: five instructions per two values (v_cvt_pk_bf16_f32,
+// the two halves widened again by one shift and one mask, v_pk_add_f32 with negated operand, v_cvt_pk_bf16_f32); element by
+// element hipcc packed only some of the pairs (263 vector instructions per 56-value epilogue instead of 224).
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& lo) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    for (int j = 0; j < 8; j += 2) {
+        const v2f x = {v[j], v[j + 1]};
+        const bf2 h = __builtin_convertvector(x, bf2);
+        const v2f d = x - __builtin_convertvector(h, v2f);
+        const bf2 l = __builtin_convertvector(d, bf2);
+        hi[j] = h[0]; hi[j + 1] = h[1];
+        lo[j] = l[0]; lo[j + 1] = l[1];
     }
 }
 // LDS-DMA (see dan_kernels_bf16p.hip::glds16): 64 lanes x 16 bytes from per-lane global addresses to lds_base + 16 * lane
@@ -163,8 +170,18 @@ __device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
 // NW = 8: a stage of its own.  NW = 4: the deferred form -- the SIMD arbiter serves the older wave first, so waves 0-3 leave the
 // conv GEMM ~7 k cycles before waves 4-7 and would wait at the barrier: they run the PREVIOUS layer's bottleneck in that wait,
 // from the image the GEMM has just read (as the fp32 kernel does).
-template <int NW>
-__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane) {
+// pre (PRE = true): all sixteen weight fragments of the matrix, requested by the caller a stage ahead (bottleneck_weights).  The
+// segment's LAST layer has no GEMM behind it to hide anything in: streamed two groups at a time its 48 MFMAs per wave sat behind four
+// exposed L2 round trips -- 9.0 k cycles under the stamps where the MFMAs are 1.5 k per SIMD (tools/segx_probe.hip, round 5).
+__device__ __forceinline__ void bottleneck_weights(bf8 (&pre)[X_KS][4], gbf8 wbot) {
+#pragma unroll
+    for (int ks = 0; ks < X_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[ks][j] = wbot[(size_t)(ks * 4 + j) * 64];
+}
+template <int NW, bool PRE = false>
+__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane,
+                                             const bf8 (*pre)[4] = nullptr) {
     constexpr int NT = 2 * X_PT, NTL = (NT + NW - 1) / NW, N = X_KS * NTL;
     asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop)
     const int n = lane & 15, g = lane >> 4;
@@ -172,7 +189,7 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
     const int nt_live = min(NT, (L + 15) >> 4);                  // tiles that hold window columns
     bf8 a[2][4], bh[2], bl[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[0][j] = wbot[(size_t)j * 64];
+    for (int j = 0; j < 4; ++j) a[0][j] = PRE ? pre[0][j] : wbot[(size_t)j * 64];
     const v4f bb0 = *(const v4f*)(bbp + 8 * g), bb1 = *(const v4f*)(bbp + 8 * g + 4);
     v4f h[NTL][2];
 #pragma unroll
@@ -188,7 +205,7 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
         const int ks = k / NTL, i = k % NTL;
         if (i == 0 && ks + 1 < X_KS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[(ks + 1) & 1][j] = wbot[(size_t)((ks + 1) * 4 + j) * 64];
+            for (int j = 0; j < 4; ++j) a[(ks + 1) & 1][j] = PRE ? pre[ks + 1][j] : wbot[(size_t)((ks + 1) * 4 + j) * 64];
         }
         if (k + 1 < N) { bh[(k + 1) & 1] = lds_read(lds, xaddr(k + 1)); bl[(k + 1) & 1] = lds_read(lds + X_LO, xaddr(k + 1)); }
         const bf8 xh = bh[k & 1], xl = bl[k & 1];
@@ -400,17 +417,13 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             XSTAMP(sb + 0);
             XFENCE();
             if (!last_layer) cst_request(l + 1, tid);
-            {
-                float bias[8];
-                lds8(bias, lc + CST_BIAS + c0);
-                const v4f b0 = {bias[0], bias[1], bias[2], bias[3]}, b1 = {bias[4], bias[5], bias[6], bias[7]};
-                if (l == a.l_begin && resumed && a.pool) {       // seeded with conv(pool) of the site (requested a row ahead)
+            // The conv bias is NOT in the accumulators: relu(acc + b) * sc + sh = max(acc, -b) * sc + (sh + b * sc), and the host
+            // stores -b and sh + b * sc in this family's constants (dan_capi.cpp) -- one v_maximum3_f32 per value where ReLU was one
+            // integer maximum, and no 28 register-pair moves per layer to spread the bias over the accumulators.  A resumed
+            // segment's first layer starts from its seed, conv(pool) of the site (requested a row ahead).
+            if (!(l == a.l_begin && resumed && a.pool)) {
 #pragma unroll
-                    for (int t = 0; t < PT; ++t) { acc[0][t] += b0; acc[1][t] += b1; }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < PT; ++t) { acc[0][t] = b0; acc[1][t] = b1; }
-                }
+                for (int t = 0; t < PT; ++t) { acc[0][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[1][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
             }
             const unsigned xb0 = cell_addr(row0 - dil, g), xb1 = cell_addr(row0, g), xb2 = cell_addr(row0 + dil, g);
             gbf8 wconv = (gbf8)(blk + WX_CONV_OFF) + 4 * q * 64 + lane;
@@ -446,16 +459,21 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 }
             };
             {
-                float sc[8], sh[8];
+                float nb[8], sc[8], sh[8];
+                lds8(nb, lc + CST_BIAS + c0);                    // -bias
                 lds8(sc, lc + CST_SCALE + c0);
-                lds8(sh, lc + CST_SHIFT + c0);
+                lds8(sh, lc + CST_SHIFT + c0);                   // shift + bias * scale
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = relu1(acc[0][t][j]); v[4 + j] = relu1(acc[1][t][j]); }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(v[j], sc[j], sh[j]);
+                    for (int j = 0; j < 8; j += 2) {
+                        const v4f& src = j < 4 ? acc[0][t] : acc[1][t];
+                        const v2f x = {src[j & 3], src[(j & 3) + 1]};
+                        const v2f m = __builtin_elementwise_maximum(x, (v2f){nb[j], nb[j + 1]});
+                        const v2f r = __builtin_elementwise_fma(m, (v2f){sc[j], sc[j + 1]}, (v2f){sh[j], sh[j + 1]});
+                        v[j] = r[0]; v[j + 1] = r[1];
+                    }
                     pack_tile(t, v);
                 }
             }
@@ -501,21 +519,32 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 __syncthreads();                                 // every read of t is done
                 XFENCE();
             }
+            // the segment's last layer runs its own bottleneck behind the barrier below: its whole weight matrix (16 fragments; the
+            // accumulators are dead by now) is requested here, ahead of the next row's requests and the barrier
+            bf8 wb_own[X_KS][4];
             store_tiles();
+            XFENCE();                                            // (behind the stores: the packed outputs' 112 registers are free again)
+            if (a.has_hw && last_layer) bottleneck_weights(wb_own, (gbf8)(blk + WX_BOT_OFF) + lane);
             if (last_layer && next_row >= 0) {
                 // requests for the NEXT row (see above): issued here, behind the layer's last use of the accumulators, they travel under
-                // the barrier, the segment's last bottleneck and the copy-out reads
-                first_request(tid);
-                if (resumed) { if (a.pool) seed_request(next_row, lane); }
-                else token_request(next_row, tid);
+                // the barrier, the segment's last bottleneck and the copy-out reads.
+                // (Opaque copies of the thread index and the row: without them hipcc forms every address of these requests -- the
+                // site index's division, three token pointers, three site pointers, seven seed pointers -- at the HEAD of the layer
+                // loop, in every layer, and parks the row's store predicates in VGPR lanes to make room: 150 of a plain layer's ~520
+                // vector instructions per wave, for loads that are issued once per row.)
+                int t2 = tid, nr = next_row;
+                asm volatile("" : "+v"(t2), "+s"(nr));
+                first_request(t2);
+                if (resumed) { if (a.pool) seed_request(nr, t2 & 63); }
+                else token_request(nr, t2);
             }
             __syncthreads();
             XFENCE();
             XSTAMP(sb + 5);
             if (a.tap && a.tap_layer == l + 1) copy_tap(CPAD);
             if (a.has_hw && last_layer)
-                bottleneck_x<NWAVE>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
-                                    a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+                bottleneck_x<NWAVE, true>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
+                                          a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane, wb_own);
             XSTAMP(sb + 6);
         }
         XSTAMP(62);
@@ -523,23 +552,29 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
         // from the image (both planes, coalesced 1-KiB stores), a barrier hands the image to the next row's DMA, the DMA is issued
         // and only then the stores.
         {
-            bf8* ydst = (bf8*)(a.y + read_idx * y_row);
-            constexpr int NC = (2 * X_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;     // 13
+            // Plane by plane, 512 chunks (32 image rows) per sweep: chunk tid & 15 of row (tid >> 4) + 32 k2 -- the swizzle term
+            // (chunk ^ row) & 15 does not change with k2, so the LDS address is ONE base + k2 * 16 KiB (immediate offsets) and the
+            // destination one base + k2 * 8 KiB.  (As one flat walk over both planes, with the plane and a clamp derived per element,
+            // the 13 reads cost 179 vector instructions of address arithmetic per row.)
+            char* ydst = (char*)(a.y + read_idx * y_row);
+            constexpr int NCP = (X_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;        // 7 sweeps per plane
             const int n8 = L * (CPAD / 8);
-            bf8 v[NC];
+            const unsigned src0 = cell_addr(P_HALO + (tid >> 4), tid & 15);
+            bf8 v[2][NCP];
 #pragma unroll
-            for (int k2 = 0; k2 < NC; ++k2) {
-                const int i = tid + k2 * SEG_THREADS;
-                const int pl = i >= n8 ? 1 : 0, ii = min(i - pl * n8, n8 - 1);
-                v[k2] = lds_read(lds + pl * X_LO, cell_addr(P_HALO + (ii >> 4), ii & 15));
-            }
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int k2 = 0; k2 < NCP; ++k2)
+                    v[pl][k2] = lds_read(lds + pl * X_LO + k2 * (32 * X_ROW_BYTES), src0);       // (rows past the window: zeros or stale, never stored)
             __syncthreads();                                     // every read of the image is done: the next row may land in it
             if (resumed && next_row >= 0) dma_read(next_row, lane);
 #pragma unroll
-            for (int k2 = 0; k2 < NC; ++k2) {
-                const int i = tid + k2 * SEG_THREADS;
-                if (i < 2 * n8) ydst[i] = v[k2];
-            }
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int k2 = 0; k2 < NCP; ++k2) {
+                    const int i = tid + k2 * SEG_THREADS;
+                    if (i < n8) *(bf8*)(ydst + (size_t)(unsigned)((pl * n8 + i) * 16)) = v[pl][k2];
+                }
         }
         XSTAMP(63);
     }
