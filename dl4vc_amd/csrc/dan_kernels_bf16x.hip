@@ -98,9 +98,11 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_base) {
 // skip_last (wave-uniform): the wave's last column tile lies past the window entirely (the second half's seventh tile when
 // L <= 208) -- its MFMAs are jumped over, 13 tiles per SIMD instead of 14.  (One branch per step; two copies of the whole walk,
 // chosen once per layer, cost 114 spilled registers where the copies' register assignments meet.)
+// fresh (wave-uniform): the accumulators hold nothing yet -- the first MFMA of each takes the literal 0 as its C operand instead of a
+// register the caller cleared (28 register-pair moves per layer and wave).
 template <int PT, int TAPS>
 __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsigned xb0, unsigned xb1, unsigned xb2, gbf8 w,
-                                       const bf8 (&first)[2][4], bool k_short, bool skip_last) {
+                                       const bf8 (&first)[2][4], bool k_short, bool skip_last, bool fresh = false) {
     constexpr int S = TAPS * X_KS, NA = 3, RING = 4, N = S * PT;
     bf8 a[NA][4], bh[RING], bl[RING];
 #pragma unroll
@@ -130,8 +132,13 @@ __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsig
             if (in < N) { bh[in % RING] = lds_read(lds, xaddr(in)); bl[in % RING] = lds_read(lds + X_LO, xaddr(in)); }
             const bf8 xh = bh[i % RING], xl = bl[i % RING];
             if (t + 1 < PT || !skip_last) {
-                acc[0][t] = mfma16(a[s % NA][0], xh, acc[0][t]);
-                acc[1][t] = mfma16(a[s % NA][2], xh, acc[1][t]);
+                if (s == 0 && fresh) {
+                    acc[0][t] = mfma16(a[s % NA][0], xh, (v4f){0.f, 0.f, 0.f, 0.f});
+                    acc[1][t] = mfma16(a[s % NA][2], xh, (v4f){0.f, 0.f, 0.f, 0.f});
+                } else {
+                    acc[0][t] = mfma16(a[s % NA][0], xh, acc[0][t]);
+                    acc[1][t] = mfma16(a[s % NA][2], xh, acc[1][t]);
+                }
                 acc[0][t] = mfma16(a[s % NA][1], xh, acc[0][t]);
                 acc[1][t] = mfma16(a[s % NA][3], xh, acc[1][t]);
                 acc[0][t] = mfma16(a[s % NA][0], xl, acc[0][t]);
@@ -170,18 +177,8 @@ __device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
 // NW = 8: a stage of its own.  NW = 4: the deferred form -- the SIMD arbiter serves the older wave first, so waves 0-3 leave the
 // conv GEMM ~7 k cycles before waves 4-7 and would wait at the barrier: they run the PREVIOUS layer's bottleneck in that wait,
 // from the image the GEMM has just read (as the fp32 kernel does).
-// pre (PRE = true): all sixteen weight fragments of the matrix, requested by the caller a stage ahead (bottleneck_weights).  The
-// segment's LAST layer has no GEMM behind it to hide anything in: streamed two groups at a time its 48 MFMAs per wave sat behind four
-// exposed L2 round trips -- 9.0 k cycles under the stamps where the MFMAs are 1.5 k per SIMD (tools/segx_probe.hip, round 5).
-__device__ __forceinline__ void bottleneck_weights(bf8 (&pre)[X_KS][4], gbf8 wbot) {
-#pragma unroll
-    for (int ks = 0; ks < X_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pre[ks][j] = wbot[(size_t)(ks * 4 + j) * 64];
-}
-template <int NW, bool PRE = false>
-__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane,
-                                             const bf8 (*pre)[4] = nullptr) {
+template <int NW>
+__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane) {
     constexpr int NT = 2 * X_PT, NTL = (NT + NW - 1) / NW, N = X_KS * NTL;
     asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop)
     const int n = lane & 15, g = lane >> 4;
@@ -189,7 +186,7 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
     const int nt_live = min(NT, (L + 15) >> 4);                  // tiles that hold window columns
     bf8 a[2][4], bh[2], bl[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[0][j] = PRE ? pre[0][j] : wbot[(size_t)j * 64];
+    for (int j = 0; j < 4; ++j) a[0][j] = wbot[(size_t)j * 64];
     const v4f bb0 = *(const v4f*)(bbp + 8 * g), bb1 = *(const v4f*)(bbp + 8 * g + 4);
     v4f h[NTL][2];
 #pragma unroll
@@ -205,7 +202,7 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
         const int ks = k / NTL, i = k % NTL;
         if (i == 0 && ks + 1 < X_KS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[(ks + 1) & 1][j] = PRE ? pre[ks + 1][j] : wbot[(size_t)((ks + 1) * 4 + j) * 64];
+            for (int j = 0; j < 4; ++j) a[(ks + 1) & 1][j] = wbot[(size_t)((ks + 1) * 4 + j) * 64];
         }
         if (k + 1 < N) { bh[(k + 1) & 1] = lds_read(lds, xaddr(k + 1)); bl[(k + 1) & 1] = lds_read(lds + X_LO, xaddr(k + 1)); }
         const bf8 xh = bh[k & 1], xl = bl[k & 1];
@@ -421,17 +418,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // stores -b and sh + b * sc in this family's constants (dan_capi.cpp) -- one v_maximum3_f32 per value where ReLU was one
             // integer maximum, and no 28 register-pair moves per layer to spread the bias over the accumulators.  A resumed
             // segment's first layer starts from its seed, conv(pool) of the site (requested a row ahead).
-            if (!(l == a.l_begin && resumed && a.pool)) {
-#pragma unroll
-                for (int t = 0; t < PT; ++t) { acc[0][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[1][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-            }
+            const bool fresh = !(l == a.l_begin && resumed && a.pool);
             const unsigned xb0 = cell_addr(row0 - dil, g), xb1 = cell_addr(row0, g), xb2 = cell_addr(row0 + dil, g);
             gbf8 wconv = (gbf8)(blk + WX_CONV_OFF) + 4 * q * 64 + lane;
-            gemm_x<PT, 3>(acc, lds, xb0, xb1, xb2, wconv, pre_a, l == 0, phantom);
+            gemm_x<PT, 3>(acc, lds, xb0, xb1, xb2, wconv, pre_a, l == 0, phantom, fresh);
             XFENCE();
             XSTAMP(sb + 1);
 
             // ---- the deferred bottleneck first (older waves), before the epilogue needs registers for the packed outputs
+            // (Tried in round 5: all sixteen weight fragments of this stage in ONE round trip -- the older waves' stage fell from 6.6 k to
+            // 4.7 k cycles under the stamps, but the 64 registers beside the live accumulators spilled 76 and the bench lost 10 %.)
             if (defer)
                 bottleneck_x<NWAVE / 2>(lds, (gbf8)(blk_of(l - 1) + WX_BOT_OFF) + lane, (const float*)(blk_of(l - 1) + WX_CST_OFF) + CST_BBOT,
                                         a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
@@ -519,12 +515,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 __syncthreads();                                 // every read of t is done
                 XFENCE();
             }
-            // the segment's last layer runs its own bottleneck behind the barrier below: its whole weight matrix (16 fragments; the
-            // accumulators are dead by now) is requested here, ahead of the next row's requests and the barrier
-            bf8 wb_own[X_KS][4];
             store_tiles();
-            XFENCE();                                            // (behind the stores: the packed outputs' 112 registers are free again)
-            if (a.has_hw && last_layer) bottleneck_weights(wb_own, (gbf8)(blk + WX_BOT_OFF) + lane);
+            // (Tried in round 5: the last layer's own bottleneck with its sixteen weight fragments requested here, ahead of the barrier --
+            // 9.0 k -> 5.5 k cycles for the stage under the stamps, but 31 spilled registers: -1.5 % in a same-box A/B.  The stage is
+            // bound by the address unit anyway: eight waves x 16 KiB of the same matrix.)
             if (last_layer && next_row >= 0) {
                 // requests for the NEXT row (see above): issued here, behind the layer's last use of the accumulators, they travel under
                 // the barrier, the segment's last bottleneck and the copy-out reads.
@@ -543,8 +537,8 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             XSTAMP(sb + 5);
             if (a.tap && a.tap_layer == l + 1) copy_tap(CPAD);
             if (a.has_hw && last_layer)
-                bottleneck_x<NWAVE, true>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
-                                          a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane, wb_own);
+                bottleneck_x<NWAVE>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
+                                    a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
             XSTAMP(sb + 6);
         }
         XSTAMP(62);
