@@ -701,87 +701,87 @@ void launch_final_pool(const float* y, float* feat, long long fs, int n_sites, i
 
 // ------------------------------------------------------------------------------------------------
 // highway compression: per layer a GEMM  [reads of the chunk] x [L*32] x [32]   (model.py:776-777,859)
-// One workgroup = 16 reads x 32 outputs; its 8 waves split K (k-group g = 2*p + (c>>4)) so that ~14
-// waves per SIMD worth of independent HBM streams exist (the h rows are read exactly once); partial
-// tiles are summed through LDS in fixed wave order (deterministic).
+// Round 5 form (see highway16_kernel in dan_kernels_bf16p.hip for the measurements behind it): one workgroup = 128 reads, wave = 16
+// reads x ALL positions (no cross-wave sum), so the 4 KiB of weights of a position are fetched once per workgroup -- wave w loads
+// those of position 8 ph + w -- into a two-phase LDS ring that all eight waves read; HW_DH positions (two 16-byte loads each) of h in
+// flight per wave.  Rounds 1-4: eight waves splitting the positions of 64 reads, each streaming its own weights from L2 -- as
+// many bytes as half its h -- and summing partial tiles through LDS: 4.3 TB/s of h.  The sums of a read are formed position by
+// position in index order (deterministic, independent of the chunking).
 // ------------------------------------------------------------------------------------------------
-constexpr int HW_WAVES = 8;
-constexpr int HW_RT = 4;                                    // 16-read row tiles per workgroup (weights amortised over 64 reads; 8 tiles spill)
+constexpr int HW_DH = 16;                                   // positions of h in flight per wave (a multiple of 8)
 __global__ __launch_bounds__(512) void highway_kernel(const float* __restrict__ h, long long hls,
                                                       const v4f* __restrict__ wc, long long wcls,
                                                       const float* __restrict__ bc, float* __restrict__ feat,
                                                       long long fs, int feat_off, int n_rows, int R, int L, int H,
                                                       const int* __restrict__ row_src) {
-    __shared__ float part[HW_WAVES][HW_RT][2][256];
+    __shared__ __attribute__((aligned(16))) char ring[2][8][4][1024];      // [phase parity][position of the phase][k-group 2 x n 2][lane * 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
     const int layer = blockIdx.y;
-    const int row0 = blockIdx.x * (16 * HW_RT);
+    const int row0 = blockIdx.x * 128 + wave * 16;
     const size_t K = (size_t)L * HPAD;
-    const int G = L * 2;
-    const int g_lo = (int)((long long)G * wave / HW_WAVES), g_hi = (int)((long long)G * (wave + 1) / HW_WAVES);
-    const float* arow[HW_RT];
+    const int row = min(row0 + r16, n_rows - 1);
+    const float* arow = h + (size_t)layer * hls + (size_t)(row_src ? row_src[row] : row) * K + kk * 4;   // skipped rows: their source's h
+    const v4f* wl = wc + (size_t)layer * wcls + lane;       // [k-group g = 2 p + (c >> 4)][n 2][lane 64]
+    v4f acc0 = splat(0.f), acc1 = splat(0.f);
+    const int n_ph = (L + 7) >> 3;
+    v4f ar[HW_DH][2];
 #pragma unroll
-    for (int i = 0; i < HW_RT; ++i) {
-        const int row = min(row0 + 16 * i + r16, n_rows - 1);
-        arow[i] = h + (size_t)layer * hls + (size_t)(row_src ? row_src[row] : row) * K + kk * 4;   // skipped rows: their source's h
+    for (int d = 0; d < HW_DH; ++d) {
+        const float* src = arow + (size_t)min(d, L - 1) * HPAD;
+        ar[d][0] = *(const v4f*)src; ar[d][1] = *(const v4f*)(src + 16);
     }
-    const v4f* wl = wc + (size_t)layer * wcls + lane;
-    v4f acc[HW_RT][2];
+    v4f wq[4];
+    {
+        const int p = min(wave, L - 1);
 #pragma unroll
-    for (int i = 0; i < HW_RT; ++i) { acc[i][0] = splat(0.f); acc[i][1] = splat(0.f); }
-    constexpr int D = 4;                                    // k-groups in flight per wave
-    v4f ar[D][HW_RT], b0[D], b1[D];
+        for (int j = 0; j < 4; ++j) wq[j] = wl[((size_t)p * 4 + j) * 64];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int g = min(g_lo + d, g_hi - 1);
-#pragma unroll
-        for (int i = 0; i < HW_RT; ++i) ar[d][i] = *(const v4f*)(arow[i] + (size_t)g * 16);
-        b0[d] = wl[((size_t)g * 2) * 64];
-        b1[d] = wl[((size_t)g * 2 + 1) * 64];
+        for (int j = 0; j < 4; ++j) *(v4f*)(&ring[0][wave][j][lane * 16]) = wq[j];
     }
-    for (int g = g_lo; g < g_hi; g += D) {
+    __syncthreads();
+    for (int ph0 = 0; ph0 < n_ph; ph0 += HW_DH / 8) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            v4f a[HW_RT];
+        for (int q = 0; q < HW_DH / 8; ++q) {                    // (unrolled: the slot of ar a position lives in is a compile-time index)
+            const int ph = ph0 + q;
+            if (ph < n_ph) {                                     // wave-uniform and the same for every wave: all reach the barrier below
+                if (ph + 1 < n_ph) {
+                    const int pn = min(8 * (ph + 1) + wave, L - 1);
 #pragma unroll
-            for (int i = 0; i < HW_RT; ++i) a[i] = ar[d][i];
-            const v4f w0 = b0[d], w1 = b1[d];
-            const int gn = min(g + d + D, g_hi - 1);
+                    for (int j = 0; j < 4; ++j) wq[j] = wl[((size_t)pn * 4 + j) * 64];
+                }
 #pragma unroll
-            for (int i = 0; i < HW_RT; ++i) ar[d][i] = *(const v4f*)(arow[i] + (size_t)gn * 16);
-            b0[d] = wl[((size_t)gn * 2) * 64];
-            b1[d] = wl[((size_t)gn * 2 + 1) * 64];
-            if (g + d < g_hi) {
+                for (int d = 0; d < 8; ++d) {
+                    const int p = 8 * ph + d;
+                    const v4f a0 = ar[q * 8 + d][0], a1 = ar[q * 8 + d][1];
+                    const float* src = arow + (size_t)min(p + HW_DH, L - 1) * HPAD;
+                    ar[q * 8 + d][0] = *(const v4f*)src; ar[q * 8 + d][1] = *(const v4f*)(src + 16);
+                    if (p < L) {
+                        const char* wr = &ring[ph & 1][d][0][lane * 16];
+                        const v4f w00 = *(const v4f*)wr, w01 = *(const v4f*)(wr + 1024), w10 = *(const v4f*)(wr + 2048), w11 = *(const v4f*)(wr + 3072);
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                        for (int sI = 0; sI < 4; ++sI) { acc0 = mfma16(a0[sI], w00[sI], acc0); acc1 = mfma16(a0[sI], w01[sI], acc1); }
 #pragma unroll
-                    for (int i = 0; i < HW_RT; ++i) {
-                        acc[i][0] = mfma16(a[i][s], w0[s], acc[i][0]);
-                        acc[i][1] = mfma16(a[i][s], w1[s], acc[i][1]);
+                        for (int sI = 0; sI < 4; ++sI) { acc0 = mfma16(a1[sI], w10[sI], acc0); acc1 = mfma16(a1[sI], w11[sI], acc1); }
                     }
+                }
+                if (ph + 1 < n_ph) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *(v4f*)(&ring[(ph + 1) & 1][wave][j][lane * 16]) = wq[j];
+                }
+                __syncthreads();
             }
         }
     }
+    // C fragment: read 4 kk + jj of the wave's sixteen, output o = 16 j + r16
 #pragma unroll
-    for (int i = 0; i < HW_RT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) part[wave][i][j][lane * 4 + jj] = acc[i][j][jj];
-    __syncthreads();
-    // element e of tile (i, j): lane = e >> 2, jj = e & 3  ->  row = row0 + 16 i + 4*(lane>>4) + jj, o = 16 j + (lane & 15)
-    for (int idx = tid; idx < HW_RT * 2 * 256; idx += 512) {
-        const int i = idx >> 9, j = (idx >> 8) & 1, e = idx & 255;
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < HW_WAVES; ++w) sum += part[w][i][j][e];
-        const int ln = e >> 2, jj = e & 3;
-        const int row = row0 + 16 * i + 4 * (ln >> 4) + jj, o = 16 * j + (ln & 15);
-        if (o < H && row < n_rows) {
-            const int site = row / R, r = row - site * R;
-            feat[(size_t)site * fs + feat_off + (size_t)layer * H * R + (size_t)o * R + r] =
-                fmaxf(sum + bc[layer * HPAD + o], 0.f);
+    for (int jj = 0; jj < 4; ++jj) {
+        const int rr = row0 + 4 * kk + jj;
+        if (rr < n_rows) {
+            const int site = rr / R, r = rr - site * R;
+            float* dst = feat + (size_t)site * fs + feat_off + (size_t)layer * H * R + r;
+            if (r16 < H) dst[(size_t)r16 * R] = fmaxf(acc0[jj] + bc[layer * HPAD + r16], 0.f);
+            if (16 + r16 < H) dst[(size_t)(16 + r16) * R] = fmaxf(acc1[jj] + bc[layer * HPAD + 16 + r16], 0.f);
         }
     }
 }
@@ -790,7 +790,7 @@ void launch_highway(const float* h, long long hls, const float* wc, long long wc
                     long long fs, int feat_off, int n_sites, int R, int L, int H, int layers, const int* row_src,
                     hipStream_t s) {
     const int n_rows = n_sites * R;
-    hipLaunchKernelGGL(highway_kernel, dim3((n_rows + 16 * HW_RT - 1) / (16 * HW_RT), layers), dim3(512), 0, s, h, hls, (const v4f*)wc,
+    hipLaunchKernelGGL(highway_kernel, dim3((n_rows + 127) / 128, layers), dim3(512), 0, s, h, hls, (const v4f*)wc,
                        wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H, row_src);
 }
 

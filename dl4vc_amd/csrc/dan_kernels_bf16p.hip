@@ -516,7 +516,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentp_kernel(Segmen
             bf8* ydst = (bf8*)(a.y + read_idx * (size_t)L * CPAD);
             // every chunk of the thread read before the first is stored (the accumulators are dead: registers are free) -- as a
             // loop of read -> wait -> store the stage was ten LDS round trips long.  (Storing y from the last epilogue's registers
-            // instead, with no copy-out stage at all, was tried: 25 spilled registers, reloads inside the conv GEMM, -6 %.)
+            // instead, with no copy-out stage at all, was tried: 25 spilled registers, reloads inside the conv GEMM, -6 %.  Round 5:
+            // this block moved in FRONT of the last bottleneck, so that its stores drain under that stage: 56 spilled registers at
+            // five tiles, 21.3 ms per launch against 18.96 in a same-box A/B -- it stays behind.)
             constexpr int NC = (P_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;     // 10
             bf8 v[NC];
 #pragma unroll
@@ -1093,14 +1095,18 @@ void launch_final_pool16(const uint16_t* y, float* feat, long long fs, int n_sit
     hipLaunchKernelGGL(final_pool16_kernel, dim3((L + 31) / 32, n_sites), dim3(256), 0, s, (const bf8*)y, feat, fs, R, L, C, row_src);
 }
 
-// highway compression from bf16 h on the bf16 matrix cores: the fp32 kernel's structure (one workgroup = 64 reads x 32 outputs, 8
-// waves split the positions, partial tiles summed through LDS in wave order), a k-group = ONE position (32 channels) = one
+// highway compression from bf16 h on the bf16 matrix cores (model.py:776-777,859).  A k-group = ONE position (32 channels) = one
 // v_mfma_f32_16x16x32_bf16 per (read tile, output tile, weight plane): a lane's 16-byte load of h IS its A fragment (read
 // lane & 15, channels 8 (lane >> 4) ..), the compression weights come as two bf16 planes (hi = bf16(w), lo = bf16(w - hi): 16
-// mantissa bits, products exact, fp32 sums).  With fp32 MFMAs (16 per position and read tile instead of 4 at half the cycles
-// each) this kernel was matrix-bound at 3.2 TB/s of h; now it streams.
-constexpr int HW16_WAVES = 8;
-constexpr int HW16_RT = 4;
+// mantissa bits, products exact, fp32 sums).
+// Round 5 form: the eight waves of a workgroup walk the SAME positions on different reads (wave = 16 reads x all positions: no
+// cross-wave sum, no 64-KiB partial buffer), so a position's four weight fragments (4 KiB) are fetched ONCE per workgroup -- wave w
+// loads those of position 8 ph + w -- into a two-phase LDS ring and read from there by all eight waves; 32 positions of h in flight
+// per wave.  Why (tools/highway_probe.hip, 128 x 301): rounds 3-4's form -- eight waves splitting the positions of 64 reads, every
+// wave streaming its own weights from L2, as many bytes as its h -- read h at 3.92 TB/s; without the weight loads 5.11, without the
+// MFMAs 3.93 (they are free), with coalesced kilobyte runs instead of 16 rows per instruction 5.3 (+4 %): the weight stream was the
+// bound.  This form: 5.6 TB/s.
+constexpr int HW16_DH = 32;                                   // positions of h in flight per wave (a multiple of 8)
 typedef __bf16 hbf8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ v4f mfma16b(hbf8 a, hbf8 b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
@@ -1108,74 +1114,70 @@ __global__ __launch_bounds__(512) void highway16_kernel(const uint16_t* __restri
                                                         long long wcls, const float* __restrict__ bc, float* __restrict__ feat,
                                                         long long fs, int feat_off, int n_rows, int R, int L, int H,
                                                         const int* __restrict__ row_src) {
-    __shared__ float part[HW16_WAVES][HW16_RT][2][256];
+    __shared__ __attribute__((aligned(16))) char ring[2][8][4][1024];      // [phase parity][position of the phase][fragment][lane * 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
     const int layer = blockIdx.y;
-    const int row0 = blockIdx.x * (16 * HW16_RT);
+    const int row0 = blockIdx.x * 128 + wave * 16;
     const size_t K = (size_t)L * HPAD;
-    const int g_lo = (int)((long long)L * wave / HW16_WAVES), g_hi = (int)((long long)L * (wave + 1) / HW16_WAVES);
-    const uint16_t* arow[HW16_RT];
-#pragma unroll
-    for (int i = 0; i < HW16_RT; ++i) {
-        const int row = min(row0 + 16 * i + r16, n_rows - 1);
-        arow[i] = h + (size_t)layer * hls + (size_t)(row_src ? row_src[row] : row) * K + kk * 8;
-    }
+    const int row = min(row0 + r16, n_rows - 1);
+    const uint16_t* arow = h + (size_t)layer * hls + (size_t)(row_src ? row_src[row] : row) * K + kk * 8;   // skipped rows: their source's h
     const hbf8* wl = wc + (size_t)layer * wcls + lane;       // [pos][n 2][plane 2][lane 64]
-    v4f acc[HW16_RT][2];
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const int n_ph = (L + 7) >> 3;
+    hbf8 ar[HW16_DH];
 #pragma unroll
-    for (int i = 0; i < HW16_RT; ++i) { acc[i][0] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-    constexpr int D = 4;                                    // positions in flight per wave
-    hbf8 ar[D][HW16_RT], bw[D][4];
+    for (int d = 0; d < HW16_DH; ++d) ar[d] = *(const hbf8*)(arow + (size_t)min(d, L - 1) * HPAD);
+    hbf8 wq[4];
+    {
+        const int p = min(wave, L - 1);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int g = min(g_lo + d, g_hi - 1);
+        for (int j = 0; j < 4; ++j) wq[j] = wl[((size_t)p * 4 + j) * 64];
 #pragma unroll
-        for (int i = 0; i < HW16_RT; ++i) ar[d][i] = *(const hbf8*)(arow[i] + (size_t)g * HPAD);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bw[d][j] = wl[((size_t)g * 4 + j) * 64];
+        for (int j = 0; j < 4; ++j) *(hbf8*)(&ring[0][wave][j][lane * 16]) = wq[j];
     }
-    for (int g = g_lo; g < g_hi; g += D) {
+    __syncthreads();
+    for (int ph0 = 0; ph0 < n_ph; ph0 += HW16_DH / 8) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            hbf8 av[HW16_RT], w4[4];
+        for (int q = 0; q < HW16_DH / 8; ++q) {                  // (unrolled: the slot of ar a position lives in is a compile-time index)
+            const int ph = ph0 + q;
+            if (ph < n_ph) {                                     // wave-uniform, and the same for every wave: the barrier below is reached by all
+                if (ph + 1 < n_ph) {
+                    const int pn = min(8 * (ph + 1) + wave, L - 1);
 #pragma unroll
-            for (int i = 0; i < HW16_RT; ++i) av[i] = ar[d][i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w4[j] = bw[d][j];
-            const int gn = min(g + d + D, g_hi - 1);
-#pragma unroll
-            for (int i = 0; i < HW16_RT; ++i) ar[d][i] = *(const hbf8*)(arow[i] + (size_t)gn * HPAD);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bw[d][j] = wl[((size_t)gn * 4 + j) * 64];
-            if (g + d < g_hi) {
-#pragma unroll
-                for (int i = 0; i < HW16_RT; ++i) {
-                    acc[i][0] = mfma16b(av[i], w4[0], acc[i][0]);
-                    acc[i][0] = mfma16b(av[i], w4[1], acc[i][0]);
-                    acc[i][1] = mfma16b(av[i], w4[2], acc[i][1]);
-                    acc[i][1] = mfma16b(av[i], w4[3], acc[i][1]);
+                    for (int j = 0; j < 4; ++j) wq[j] = wl[((size_t)pn * 4 + j) * 64];
                 }
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const int p = 8 * ph + d;
+                    const hbf8 av = ar[q * 8 + d];
+                    ar[q * 8 + d] = *(const hbf8*)(arow + (size_t)min(p + HW16_DH, L - 1) * HPAD);
+                    if (p < L) {
+                        const char* wr = &ring[ph & 1][d][0][lane * 16];
+                        const hbf8 w0 = *(const hbf8*)wr, w1 = *(const hbf8*)(wr + 1024), w2 = *(const hbf8*)(wr + 2048), w3 = *(const hbf8*)(wr + 3072);
+                        acc0 = mfma16b(av, w0, acc0);
+                        acc0 = mfma16b(av, w1, acc0);
+                        acc1 = mfma16b(av, w2, acc1);
+                        acc1 = mfma16b(av, w3, acc1);
+                    }
+                }
+                if (ph + 1 < n_ph) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *(hbf8*)(&ring[(ph + 1) & 1][wave][j][lane * 16]) = wq[j];
+                }
+                __syncthreads();
             }
         }
     }
+    // C fragment: read 4 kk + jj of the wave's sixteen, output o = 16 j + r16
 #pragma unroll
-    for (int i = 0; i < HW16_RT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) part[wave][i][j][lane * 4 + jj] = acc[i][j][jj];
-    __syncthreads();
-    for (int idx = tid; idx < HW16_RT * 2 * 256; idx += 512) {
-        const int i = idx >> 9, j = (idx >> 8) & 1, e = idx & 255;
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < HW16_WAVES; ++w) sum += part[w][i][j][e];
-        const int ln = e >> 2, jj = e & 3;
-        const int row = row0 + 16 * i + 4 * (ln >> 4) + jj, o = 16 * j + (ln & 15);
-        if (o < H && row < n_rows) {
-            const int site = row / R, r = row - site * R;
-            feat[(size_t)site * fs + feat_off + (size_t)layer * H * R + (size_t)o * R + r] = fmaxf(sum + bc[layer * HPAD + o], 0.f);
+    for (int jj = 0; jj < 4; ++jj) {
+        const int rr = row0 + 4 * kk + jj;
+        if (rr < n_rows) {
+            const int site = rr / R, r = rr - site * R;
+            float* dst = feat + (size_t)site * fs + feat_off + (size_t)layer * H * R + r;
+            if (r16 < H) dst[(size_t)r16 * R] = fmaxf(acc0[jj] + bc[layer * HPAD + r16], 0.f);
+            if (16 + r16 < H) dst[(size_t)(16 + r16) * R] = fmaxf(acc1[jj] + bc[layer * HPAD + 16 + r16], 0.f);
         }
     }
 }
@@ -1183,7 +1185,7 @@ __global__ __launch_bounds__(512) void highway16_kernel(const uint16_t* __restri
 void launch_highway16(const uint16_t* h, long long hls, const float* wc16, long long wcls, const float* bc, float* feat, long long fs,
                       int feat_off, int n_sites, int R, int L, int H, int layers, const int* row_src, hipStream_t s) {
     const int n_rows = n_sites * R;
-    hipLaunchKernelGGL(highway16_kernel, dim3((n_rows + 16 * HW16_RT - 1) / (16 * HW16_RT), layers), dim3(512), 0, s, h, hls,
+    hipLaunchKernelGGL(highway16_kernel, dim3((n_rows + 127) / 128, layers), dim3(512), 0, s, h, hls,
                        (const hbf8*)wc16, wcls / 4, bc, feat, fs, feat_off, n_rows, R, L, H, row_src);
 }
 
