@@ -127,6 +127,10 @@ void launch_highway_bwd(const float* dfeat, const float* feat, long long fs, int
 void launch_highway_dhw(const float* dfeat, const float* feat, long long fs, int feat_off, float* dhw, int n_sites, int R, int H,
                         int layers, hipStream_t s);
 void launch_highway_wc_transpose(const float* t, float* g_wc, int L, int H, hipStream_t s);
+// the highway compression's backward, all layers per launch: dh[l][row][p][c] = sum_o dhw[l][row][o] WcT[l][p][c][o];
+// gWc[l] (torch layout (o, c, p) at g_base + w_off[l]) = sum_row dhw[l][row][o] h[l][row][p][c]
+void launch_highway_dh(const float* dhw, const float* wct, float* dh, int n_rows, int L, int layers, hipStream_t s);
+void launch_highway_gwc(const float* dhw, const float* h, float* g_base, const long long* w_off, int n_rows, int L, int H, int layers, hipStream_t s);
 void launch_highway_bias_grad_all(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial /*[layers][64][HPAD]*/,
                                   float* g_base, const long long* g_off_on_device, int n_sites, int R, int H, int layers, hipStream_t s);
 void launch_highway_bias_grad(const float* dfeat, const float* feat, long long fs, int feat_off, float* partial /*[64][HPAD]*/,

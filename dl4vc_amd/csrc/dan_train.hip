@@ -12,6 +12,7 @@
 // staged per half read, split-K partials reduced in a fixed order.  Every reduction is deterministic (no atomics).
 #include "dan_device.h"
 #include "dan_train.h"
+#include <type_traits>
 
 #include <algorithm>
 
@@ -1686,6 +1687,156 @@ __global__ __launch_bounds__(256) void highway_wc_transpose_kernel(const float* 
 
 void launch_highway_wc_transpose(const float* t, float* g_wc, int L, int H, hipStream_t s) {
     hipLaunchKernelGGL(highway_wc_transpose_kernel, dim3((H * H * L + 255) / 256), dim3(256), 0, s, t, g_wc, L, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// highway compression backward on the matrix cores, one launch each for all layers (round 5; they were 7 x 2 launches of the generic
+// tiled GEMM -- K = 32 and a 165-MB output at 2.6 TB/s; K = rows with both operands row-slow at 1.8 TB/s, split-K partials, a
+// transpose launch per layer).
+//   dh[l][row][p][c]  = sum_o dhw[l][row][o] Wc[l][o][c][p]            (write stream: highway_dh_kernel)
+//   gWc[l][o][c][p]   = sum_row dhw[l][row][o] h[l][row][p][c]         (read stream of h: highway_gwc_kernel)
+// ------------------------------------------------------------------------------------------------
+// dh: the forward highway kernel's structure (dan_kernels.hip) with the roles turned: wave = 16 reads x all positions, the reads'
+// dhw (16 x 32) sits in the wave's registers for the whole walk as the B operand, the position's WcT[p] (32 c x 32 o = 4 KiB) is the
+// A operand, fetched once per workgroup through a two-phase LDS ring; a lane ends up with four consecutive c of one read: one
+// 16-byte store per channel tile, a read's 128 bytes of a position complete behind two instructions, positions in order.
+__global__ __launch_bounds__(512) void highway_dh_kernel(const float* __restrict__ dhw, const float* __restrict__ wct, float* __restrict__ dh,
+                                                         int n_rows, int L) {
+    __shared__ __attribute__((aligned(16))) char ring[2][8][4][1024];      // [phase parity][position of the phase][c tile 2 x o group 2][lane * 16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int layer = blockIdx.y;
+    const int row0 = blockIdx.x * 128 + wave * 16;
+    const int row = min(row0 + i16, n_rows - 1);
+    const float* brow = dhw + ((size_t)layer * n_rows + row) * HPAD + kk * 4;
+    const v4f b0 = *(const v4f*)brow, b1 = *(const v4f*)(brow + 16);       // o groups 0..15, 16..31 of this lane's read
+    // A fragment (c tile mt, o group g) of position p: lane (c16 = i16, kk) <- WcT[p][16 mt + c16][16 g + 4 kk ..]
+    const float* wl = wct + (size_t)layer * L * HPAD * HPAD + (size_t)i16 * HPAD + kk * 4;
+    auto wfrag = [&](int p, int j) { return *(const v4f*)(wl + (size_t)p * HPAD * HPAD + (j >> 1) * 16 * HPAD + (j & 1) * 16); };
+    float* drow = dh + ((size_t)layer * n_rows + row) * (size_t)L * HPAD + kk * 4;
+    const bool live = row0 + i16 < n_rows;
+    const int n_ph = (L + 7) >> 3;
+    v4f wq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wq[j] = wfrag(min(wave, L - 1), j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(v4f*)(&ring[0][wave][j][lane * 16]) = wq[j];
+    __syncthreads();
+    for (int ph = 0; ph < n_ph; ++ph) {
+        if (ph + 1 < n_ph) {
+            const int pn = min(8 * (ph + 1) + wave, L - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[j] = wfrag(pn, j);
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int p = 8 * ph + d;
+            if (p < L) {
+                const char* wr = &ring[ph & 1][d][0][lane * 16];
+                const v4f a00 = *(const v4f*)wr, a01 = *(const v4f*)(wr + 1024), a10 = *(const v4f*)(wr + 2048), a11 = *(const v4f*)(wr + 3072);
+                v4f c0 = splat(0.f), c1 = splat(0.f);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) { c0 = mfma16(a00[sI], b0[sI], c0); c1 = mfma16(a10[sI], b0[sI], c1); }
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) { c0 = mfma16(a01[sI], b1[sI], c0); c1 = mfma16(a11[sI], b1[sI], c1); }
+                if (live) {
+                    *(v4f*)(drow + (size_t)p * HPAD) = c0;               // c = 4 kk .. 4 kk + 3
+                    *(v4f*)(drow + (size_t)p * HPAD + 16) = c1;          // c = 16 + 4 kk ..
+                }
+            }
+        }
+        if (ph + 1 < n_ph) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(v4f*)(&ring[(ph + 1) & 1][wave][j][lane * 16]) = wq[j];
+        }
+        __syncthreads();
+    }
+}
+
+void launch_highway_dh(const float* dhw, const float* wct, float* dh, int n_rows, int L, int layers, hipStream_t s) {
+    hipLaunchKernelGGL(highway_dh_kernel, dim3((n_rows + 127) / 128, layers), dim3(512), 0, s, dhw, wct, dh, n_rows, L);
+}
+
+// gWc: one workgroup = (layer, eight positions), wave = ONE position, all reads in order (no split: one accumulator chain per
+// element, deterministic).  MFMA k = the read: of a block of 16 reads lane (i16, kk) supplies reads 4 s + kk (s = the MFMA of the
+// group) -- A = dhw[read][o] from an LDS copy of the block that all eight waves share, B = h[read][p][c] by one 4-byte load per lane
+// and MFMA (a wave instruction moves 4 reads x 64 bytes; 32 of them in flight).  The (o, c) block of the position goes straight
+// to the torch layout gWc[o][c][p].
+constexpr int GW_ROWS = 64;                                   // reads per staged dhw block
+__global__ __launch_bounds__(512) void highway_gwc_kernel(const float* __restrict__ dhw, const float* __restrict__ h, float* __restrict__ g_base,
+                                                          const long long* __restrict__ w_off, int n_rows, int L, int H) {
+    __shared__ __attribute__((aligned(16))) float sd[2][GW_ROWS * HPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int layer = blockIdx.y;
+    const int p = blockIdx.x * 8 + wave;
+    const bool pos_ok = p < L;
+    const int pc = min(p, L - 1);
+    const float* hl = h + (size_t)layer * n_rows * (size_t)L * HPAD + (size_t)pc * HPAD + i16;
+    const float* dl = dhw + (size_t)layer * n_rows * HPAD;
+    v4f acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = splat(0.f);
+    const int n_blk = (n_rows + GW_ROWS - 1) / GW_ROWS;
+    auto stage = [&](int blk, int buf) {                          // 64 reads x 32 floats: one 16-byte load per thread, zero past the end
+        const int r = blk * GW_ROWS + (tid >> 3);
+        const v4f v = r < n_rows ? *(const v4f*)(dl + (size_t)r * HPAD + (tid & 7) * 4) : splat(0.f);
+        *(v4f*)(&sd[buf][(tid >> 3) * HPAD + (tid & 7) * 4]) = v;
+    };
+    // h of a block: 4 groups of 16 reads x (s 4) x (c tile 2) one-float loads
+    float hb[2][4][4][2];
+    auto request = [&](int blk, int slot) {
+#pragma unroll
+        for (int gI = 0; gI < 4; ++gI)
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const int r = min(blk * GW_ROWS + gI * 16 + 4 * sI + kk, n_rows - 1);       // (clamped reads multiply a zero of the dhw block)
+                const float* src = hl + (size_t)r * L * HPAD;
+                hb[slot][gI][sI][0] = src[0];
+                hb[slot][gI][sI][1] = src[16];
+            }
+    };
+    stage(0, 0);
+    request(0, 0);
+    __syncthreads();
+    auto block = [&](int blk, auto slot_c) {                      // (the slot is a compile-time index: the loop below walks pairs)
+        constexpr int cur = decltype(slot_c)::value;
+        if (blk + 1 < n_blk) { stage(blk + 1, cur ^ 1); request(blk + 1, cur ^ 1); }
+#pragma unroll
+        for (int gI = 0; gI < 4; ++gI)
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float* ar = &sd[cur][(gI * 16 + 4 * sI + kk) * HPAD + i16];
+                const float a0 = ar[0], a1 = ar[16];
+                const float x0 = hb[cur][gI][sI][0], x1 = hb[cur][gI][sI][1];
+                acc[0][0] = mfma16(a0, x0, acc[0][0]);
+                acc[0][1] = mfma16(a0, x1, acc[0][1]);
+                acc[1][0] = mfma16(a1, x0, acc[1][0]);
+                acc[1][1] = mfma16(a1, x1, acc[1][1]);
+            }
+        __syncthreads();
+    };
+    for (int blk = 0; blk < n_blk; blk += 2) {
+        block(blk, std::integral_constant<int, 0>{});
+        if (blk + 1 < n_blk) block(blk + 1, std::integral_constant<int, 1>{});
+    }
+    if (!pos_ok) return;
+    float* g = g_base + w_off[layer];                          // torch layout (o, c, p)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 16 * x + 4 * kk + j, c = 16 * y + i16;
+                if (o < H && c < H) g[((size_t)o * H + c) * L + p] = acc[x][y][j];
+            }
+}
+
+void launch_highway_gwc(const float* dhw, const float* h, float* g_base, const long long* w_off, int n_rows, int L, int H, int layers, hipStream_t s) {
+    hipLaunchKernelGGL(highway_gwc_kernel, dim3((L + 7) / 8, layers), dim3(512), 0, s, dhw, h, g_base, w_off, n_rows, L, H);
 }
 
 constexpr int HB_ROWS = 8;

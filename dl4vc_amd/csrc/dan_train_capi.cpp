@@ -73,6 +73,7 @@ struct dan_trainer {
     std::vector<int> wino_layer;
     PackJob* d_pack_jobs = nullptr;          // the step's re-packing as one launch (build_pack_jobs)
     long long* d_cmpb_off = nullptr;         // [layers] offsets of the compression biases in the flat buffers
+    long long* d_cmpw_off = nullptr;         // [layers] offsets of the compression weights
     int n_pack_jobs = 0, n_pack_blocks = 0;
     std::vector<int> lazy_x;                 // [l] 1: x_l = bn(a_l) is never written -- its consumers form it from a_l as they load
     float* d_xtap = nullptr;                 // scratch for the "act:x<l>" debug tap of such a layer
@@ -489,6 +490,9 @@ int build_pack_jobs(dan_trainer* t) {
         int rc2 = talloc(t, &t->d_cmpb_off, off.size(), false);
         if (rc2) return rc2;
         HIPT(t, hipMemcpy(t->d_cmpb_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+        for (int l = 0; l < c.layers; ++l) off[l] = t->params[t->layers[l].cmp_w].off;
+        if ((rc2 = talloc(t, &t->d_cmpw_off, off.size(), false))) return rc2;
+        HIPT(t, hipMemcpy(t->d_cmpw_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
     }
     int blocks = 0;
     for (PackJob& q : jobs) { q.first_block = blocks; blocks += pack_job_blocks(q); }
@@ -691,20 +695,11 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
     // highway compression
     const int hw_off = 2 * c.c_final * L;
     if (H > 0) {
-        // dhw = dfeat_hw * (feat_hw > 0) as [layer][row][HPAD]; then per layer two tiled MFMA GEMMs (launch_gemm) and a column sum
-        const int NE = L * HPAD;
+        // dhw = dfeat_hw * (feat_hw > 0) as [layer][row][HPAD]; then one launch for every layer's dh (a 165-MB write stream per layer at
+        // 64 sites) and one for every layer's weight gradient (h read once, no split, straight into the torch layout)
         launch_highway_dhw(t->d_dfeat, t->d_feat, t->F_stride, hw_off, t->d_dhw, B, R, H, NL, s);
-        for (int l = 0; l < NL; ++l) {
-            const LayerP& lp = t->layers[l];
-            const float* dhw = t->d_dhw + (size_t)l * n_rows * HPAD;
-            // dh[row][e] = sum_o dhw[row][o] WcT[e][o]
-            launch_gemm(dhw, HPAD, 0, t->d_wct + (size_t)l * L * HPAD * HPAD, HPAD, 0, nullptr, t->d_dh + (size_t)l * h_layer, NE, n_rows, NE, HPAD, 0,
-                        nullptr, 0, s);
-            // gWcT[o][e] = sum_rows dhw[row][o] h[row][e]   (K = rows: split-K), then to the torch layout (o, c, p)
-            launch_gemm(dhw, HPAD, 1, t->d_h + (size_t)l * h_layer, NE, 1, nullptr, t->d_hw_partial, NE, HPAD, NE, n_rows, 0, t->d_split_hw,
-                        t->split_hw_floats, s);
-            launch_highway_wc_transpose(t->d_hw_partial, gp(t, lp.cmp_w), L, H, s);
-        }
+        launch_highway_dh(t->d_dhw, t->d_wct, t->d_dh, n_rows, L, NL, s);
+        launch_highway_gwc(t->d_dhw, t->d_h, t->G, t->d_cmpw_off, n_rows, L, H, NL, s);
         // the compression biases' gradients of all layers (column sums of dhw) in two launches
         launch_highway_bias_grad_all(t->d_dfeat, t->d_feat, t->F_stride, hw_off, t->d_bias_partial, t->G, t->d_cmpb_off, B, R, H, NL, s);
     }
