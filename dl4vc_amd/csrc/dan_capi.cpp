@@ -306,8 +306,8 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     if (c.reads < 1) return fail(nullptr, DAN_ERR_INVALID_ARG, "reads must be >= 1");
     if (c.precision < 0 || c.precision > 2)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "precision %d unknown (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)", c.precision);
-    // precision 0 above MPOS columns: every read as two overlapping units (dan_kernels.h plan_units; checked per segment below)
-    const int max_len = c.precision == 1 ? MPOS : P_LMAX;
+    // precisions 0 and 1 above MPOS columns: every read as two overlapping units (dan_kernels.h plan_units; checked per segment below)
+    const int max_len = P_LMAX;
     if (c.length < 8 || c.length > max_len)
         return fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported by the LDS-resident path at precision %d (8..%d)", c.length, c.precision, max_len);
     if (c.c_init < 1 || c.c_init > CPAD || c.c_final < 1 || c.c_final > CPAD)
@@ -346,7 +346,7 @@ int dan_create(const dan_config* cfg, dan_t** out) {
         // the feature matrix, FC workspaces and weights take their share of the rest)
         // (precision 2 keeps y and h as bf16: half the bytes per site, twice the sites per chunk -- 1024 at 128 x 301)
         const double elem = c.precision == 2 ? 2.0 : 4.0;
-        const double y_copies = (c.precision == 0 && c.length > MPOS) ? 2.0 : 1.0;       // (two units per read: y out of place)
+        const double y_copies = (c.precision != 2 && c.length > MPOS) ? 2.0 : 1.0;       // (two units per read: y out of place)
         const double per_site = (double)c.reads * c.length * (y_copies * CPAD + (double)c.layers * (c.bottleneck > 0 ? HPAD : 0)) * elem;
         double budget = 48e9;
         size_t free_b = 0, total_b = 0;
@@ -376,13 +376,13 @@ int dan_create(const dan_config* cfg, dan_t** out) {
     for (int l1 = 1; l1 <= c.layers; ++l1)
         if (l1 == c.layers || pool_after(c, l1)) { h->seg_begin.push_back(b); h->seg_end.push_back(l1); b = l1; }
     h->n_segments = (int)h->seg_begin.size();
-    if (c.precision == 0 && c.length > MPOS) {
+    if (c.precision != 2 && c.length > MPOS) {
         // every segment's two units must fit the 208-row image: half the window + the segment's receptive-field radius
         for (int sg = 0; sg < h->n_segments; ++sg) {
             SegmentArgs probe{};
             const int halo = segment_halo(c, h->seg_begin[sg], h->seg_end[sg]);
             if (!plan_units(probe, c.length, halo)) {
-                const int rc = fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported at precision 0 with these dilations: layers %d..%d reach %d "
+                const int rc = fail(nullptr, DAN_ERR_INVALID_ARG, "length %d unsupported at precisions 0 and 1 with these dilations: layers %d..%d reach %d "
                                     "columns sideways, half the window plus that exceeds the %d-column LDS image", c.length,
                                     h->seg_begin[sg] + 1, h->seg_end[sg], halo, MPOS);
                 delete h;
@@ -737,7 +737,7 @@ static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qu
                 float* const y_in = y_seg;                   // the previous segment's output
                 if (h->split) y_seg = (y_seg == h->d_y) ? h->d_y2 : h->d_y;
                 a.y = y_in; a.y_out = y_seg;
-                if (c.precision == 0 && !plan_units(a, L, segment_halo(c, a.l_begin, a.l_end)))
+                if (c.precision != 2 && !plan_units(a, L, segment_halo(c, a.l_begin, a.l_end)))
                     return fail(h, DAN_ERR_STATE, "unit plan failed for segment %d", sg);
                 a.pool = sg > 0 ? h->d_pool : nullptr;
                 a.h = h->d_h; a.h_layer_stride = h_layer_stride;
@@ -757,7 +757,9 @@ static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qu
                     b.dil_mid = a.dil_mid; b.dil_final = a.dil_final; b.res_mask = a.res_mask; b.has_hw = a.has_hw;
                     b.R = a.R; b.L = a.L; b.reads = a.reads; b.qual = a.qual; b.strand = a.strand; b.ref = a.ref;
                     b.ref_mask = a.ref_mask; b.var_mask = a.var_mask; b.emb = a.emb; b.pe = a.pe;
-                    b.y = (uint16_t*)h->d_y; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = h->d_h; b.h_layer_stride = a.h_layer_stride;
+                    b.y = (uint16_t*)a.y; b.y_out = (uint16_t*)a.y_out; b.pool = sg > 0 ? h->d_cp : nullptr; b.h = h->d_h; b.h_layer_stride = a.h_layer_stride;
+                    b.units = a.units; b.Lw = a.Lw;               // (plan_units above: b.L = the unit length)
+                    for (int u = 0; u < 2; ++u) { b.u_off[u] = a.u_off[u]; b.u_len[u] = a.u_len[u]; b.own_lo[u] = a.own_lo[u]; b.own_hi[u] = a.own_hi[u]; }
                     b.tap = a.tap; b.tap_layer = a.tap_layer; b.work = a.work; b.work_count = a.work_count;
                     b.stagger = -1;                              // (the launcher's own start offsets)
                     launch_segmentx(b, ns, h->n_cus, s);
@@ -775,7 +777,7 @@ static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qu
                 if (sg + 1 < h->n_segments) {
                     rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
                     if (h->use_p || h->use_x) {
-                        if (h->use_x) launch_read_meanx((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
+                        if (h->use_x) launch_read_meanx((const uint16_t*)y_seg, h->d_pool, ns, R, L, h->d_rowsrc, s);
                         else launch_read_mean16((const uint16_t*)h->d_y, h->d_pool, ns, R, L, h->d_rowsrc, s);
                         const int ln = h->seg_begin[sg + 1];                      // 0-based layer behind the pool: its dilation
                         launch_conv_pool(h->d_pool, h->d_wpool + (size_t)(sg + 1) * CPAD * 3 * CPAD, h->d_zero, h->d_cols, h->d_cp, ns, L,
@@ -788,7 +790,7 @@ static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qu
             float* feat = h->d_feat + (size_t)c0 * h->F_stride;
             EventPair ev{};
             int rc = prof_begin(h, "pool", s, &ev); if (rc) return rc;
-            if (h->use_x) launch_final_poolx((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
+            if (h->use_x) launch_final_poolx((const uint16_t*)y_seg, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             else if (h->use_p) launch_final_pool16((const uint16_t*)h->d_y, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             else launch_final_pool(y_seg, feat, h->F_stride, ns, R, L, c.c_final, h->d_rowsrc, s);
             rc = prof_end(h, "pool", s, &ev); if (rc) return rc;

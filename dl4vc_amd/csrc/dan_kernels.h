@@ -75,15 +75,18 @@ struct SegmentArgs {
     // segment's receptive-field radius (the sum of its layers' dilations): the zero padding the kernel applies at a unit's inner
     // cut is wrong there and leaks one dilation further per layer, never into an owned column.  L is then unused; Lw = the
     // window = the position stride of reads / ref / pe / y / pool / h / tap.  y_out != y: the other unit reads its overlap from
-    // y while this one stores (units == 1: Lw == L, y_out == y, in place as ever).
+    // y while this one stores (units == 1: Lw == L, y_out == y, in place as ever).  With units == 2, L = the units' common length.
     int units, Lw;
     int u_off[2], u_len[2], own_lo[2], own_hi[2];
     float* y_out;
 };
 
-// Windows above MPOS columns: two units per read (see SegmentArgs).  halo = the segment's receptive-field radius.  Returns false
-// when a unit would not fit (window > 2 (MPOS - halo)).  For Lw <= MPOS: one unit, the whole window.
-inline bool plan_units(SegmentArgs& a, int Lw, int halo) {
+// Windows above MPOS columns: two units per read (see SegmentArgs; SegmentXArgs carries the same fields).  halo = the segment's
+// receptive-field radius.  Returns false when a unit would not fit (window > 2 (MPOS - halo)).  For Lw <= MPOS: one unit, the whole
+// window.  Both units have the SAME length (for an odd window the second starts one column earlier): the bf16x3 kernel keeps its
+// image across rows and relies on the rows past a unit's length staying zero.
+template <class Args>
+inline bool plan_units(Args& a, int Lw, int halo) {
     a.Lw = Lw;
     if (Lw <= MPOS) {
         a.units = 1; a.L = Lw;
@@ -92,10 +95,11 @@ inline bool plan_units(SegmentArgs& a, int Lw, int halo) {
         return true;
     }
     const int mid = (Lw + 1) / 2;                                 // unit 0 owns [0, mid), unit 1 owns [mid, Lw)
-    if (mid + halo > MPOS || Lw - mid + halo > MPOS) return false;
-    a.units = 2; a.L = 0;
-    a.u_off[0] = 0; a.u_len[0] = mid + halo; a.own_lo[0] = 0; a.own_hi[0] = mid;
-    a.u_off[1] = mid - halo; a.u_len[1] = Lw - (mid - halo); a.own_lo[1] = halo; a.own_hi[1] = a.u_len[1];
+    const int len = mid + halo;
+    if (len > MPOS || len > Lw) return false;
+    a.units = 2; a.L = len;
+    a.u_off[0] = 0; a.u_len[0] = len; a.own_lo[0] = 0; a.own_hi[0] = mid;
+    a.u_off[1] = Lw - len; a.u_len[1] = len; a.own_lo[1] = mid - (Lw - len); a.own_hi[1] = len;
     return true;
 }
 
@@ -169,7 +173,7 @@ void launch_highway16(const uint16_t* h, long long h_layer_stride, const float* 
 // arrives by LDS-DMA and the copy-out is a plain copy), h as fp32.
 constexpr int X_PT = 7;                   // 16-column tiles per wave: wave = (channel quarter, position half), 2 x 7 x 16 = 224 columns
 constexpr int X_COLS = 2 * X_PT * 16;
-constexpr int X_LMAX = MPOS;              // 208 (the 14th tile is a phantom: skipped when L <= 208)
+constexpr int X_LMAX = MPOS;              // 208 columns per LDS-resident unit (the 14th tile is a phantom: skipped when L <= 208); longer windows: two units
 constexpr int X_ROWS = X_COLS + 2 * P_HALO;
 constexpr int X_ROW_BYTES = 2 * P_ROW_BYTES;              // one image row: the hi plane's 16 chunks, then the lo plane's
 constexpr int X_LO = P_ROW_BYTES;
@@ -209,6 +213,10 @@ struct SegmentXArgs {
     int stagger;                 // filled by the launcher: start offset per workgroup index, in units of 256 cycles
     const int* work;
     const int* work_count;
+    // windows of 209..304 columns: two units per read, exactly as in SegmentArgs (plan_units); y_out != y then
+    int units, Lw;
+    int u_off[2], u_len[2], own_lo[2], own_hi[2];
+    uint16_t* y_out;
 };
 void launch_segmentx(const SegmentXArgs& a, int n_sites, int n_cus, hipStream_t s);
 // the two reductions over reads from the two-plane y (value = hi + lo, summed in fp32 in read order)

@@ -177,8 +177,10 @@ __device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
 // NW = 8: a stage of its own.  NW = 4: the deferred form -- the SIMD arbiter serves the older wave first, so waves 0-3 leave the
 // conv GEMM ~7 k cycles before waves 4-7 and would wait at the barrier: they run the PREVIOUS layer's bottleneck in that wait,
 // from the image the GEMM has just read (as the fp32 kernel does).
+// p_lo, p_hi: the columns that are stored (a unit of a split read stores its own columns only; default: the whole window)
 template <int NW>
-__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane) {
+__device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane,
+                                             int p_lo = 0, int p_hi = 1 << 30) {
     constexpr int NT = 2 * X_PT, NTL = (NT + NW - 1) / NW, N = X_KS * NTL;
     asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop)
     const int n = lane & 15, g = lane >> 4;
@@ -216,7 +218,7 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
         const int tl = wave + NW * i, p = 16 * tl + n;
-        if (tl < NT && p < L) {
+        if (tl < NT && p < L && p >= p_lo && p < p_hi) {
             v4f h0 = h[i][0], h1 = h[i][1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { h0[j] = relu1(h0[j]); h1[j] = relu1(h1[j]); }
@@ -227,13 +229,20 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
     }
 }
 
+// SPLIT = true: windows of 209..304 columns, every read as two overlapping units of the SAME length a.L (SegmentXArgs::units == 2,
+// dan_kernels.h plan_units -- the fp32 kernel's scheme): a work item is (row, unit), position-indexed pointers are offset to the
+// unit's first column of a window of Lw columns, the agreement predicates look at the whole window, a unit stores (y, h, tap) its
+// own columns only and y crosses segments out of place.  SPLIT = false is the kernel as it was.
+struct XUnit { int off, lo, hi; };                              // first window column, own columns [lo, hi) (unit-relative)
+template <bool SPLIT>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(SegmentXArgs a) {
     constexpr int PT = X_PT;
     __shared__ __attribute__((aligned(16))) char lds[X_LDS_BYTES];
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int q = wave & 3, half = wave >> 2;
-    const int L = a.L;
+    const int L = a.L;                                           // columns of one LDS-resident unit (the whole window unless SPLIT)
+    const int Lw = SPLIT ? a.Lw : L;                             // the window: position stride of every tensor
     const int pbase = half * (PT * 16);
     const bool phantom = pbase + 16 * (PT - 1) >= L;             // (wave-uniform) the wave's last tile lies past the window entirely
     // behind the two planes: the per-channel constants (bias, scale, shift, bres: 512 floats) of the current layer and of the
@@ -245,33 +254,40 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
     __syncthreads();
 
     // persistent walk over XCD-contiguous slices of whole sites (see dan_kernels_bf16p.hip)
-    const int n_work = a.work_count ? *a.work_count : a.n_rows;
-    const int slice = a.work_count ? (n_work + 7) / 8 : a.slice_rows;
+    constexpr int UNITS = SPLIT ? 2 : 1;
+    const int n_work = (a.work_count ? *a.work_count : a.n_rows) * UNITS;
+    const int slice = a.work_count ? (n_work + 7) / 8 : a.slice_rows * UNITS;
     const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, nj = gridDim.x >> 3;
     auto row_of = [&](int k) {
         const int wk = xcd * slice + k;
         if (k >= slice || wk >= n_work) return -1;
-        return a.work_count ? a.work[wk] : wk;
+        const int wr = SPLIT ? wk >> 1 : wk;
+        return a.work_count ? a.work[wr] : wr;
+    };
+    auto unit_of = [&](int k) -> XUnit {                         // (wave-uniform)
+        if (!SPLIT) return XUnit{0, 0, L};
+        const int u = (xcd * slice + k) & 1;
+        return u ? XUnit{a.u_off[1], a.own_lo[1], a.own_hi[1]} : XUnit{a.u_off[0], a.own_lo[0], a.own_hi[0]};
     };
     const bool resumed = a.l_begin > 0;
-    const size_t y_row = (size_t)2 * L * CPAD;                  // bf16 elements of one read's two planes
+    const size_t y_row = (size_t)2 * Lw * CPAD;                 // bf16 elements of one read's two planes
     // a resumed segment's input: both planes of the read by LDS-DMA (1-KiB pieces of 4 rows; the chunk swizzle goes on the
     // per-lane SOURCE address, the destination is lane-linear)
-    auto dma_read = [&](int row_index, int lane) {
-        const char* ysrc = (const char*)(a.y + (size_t)row_index * y_row);
+    auto dma_read = [&](int row_index, int u_off, int lane) {
+        const char* ysrc = (const char*)(a.y + (size_t)row_index * y_row) + (size_t)u_off * P_ROW_BYTES;
         char* img = lds + P_HALO * X_ROW_BYTES;
         // a 1-KiB piece = two image rows: lane -> row 2 kb + (lane >> 5), plane (lane >> 4) & 1, stored chunk lane & 15
         const int pl = (lane >> 4) & 1;
         for (int kb = wave; kb * 2 < L; kb += NWAVE) {
             const int p = 2 * kb + (lane >> 5), r = P_HALO + p;
-            if (p < L) glds16(ysrc + ((size_t)pl * L + p) * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
+            if (p < L) glds16(ysrc + ((size_t)pl * Lw + p) * P_ROW_BYTES + (((lane ^ r) & 15) << 4), img + kb * 1024);
         }
     };
     // ... and the seed of its first layer's accumulators: conv(pool) of the read's site (launch_conv_pool, model.py:742)
     v4f acc[2][PT];
-    auto seed_request = [&](int row_index, int lane) {
+    auto seed_request = [&](int row_index, int u_off, int lane) {
         const int n = lane & 15, g = lane >> 4;
-        const float* cp = a.pool + (size_t)(row_index / a.R) * (size_t)L * CPAD + 32 * q + 8 * g;
+        const float* cp = a.pool + ((size_t)(row_index / a.R) * (size_t)Lw + u_off) * CPAD + 32 * q + 8 * g;
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const int p = pbase + 16 * t + n;
@@ -286,27 +302,34 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
     v4f creq;
     bf8 pre_a[2][4];
     int tk_tok = 0, tk_q = 0, tk_st = 0, tk_rf = 0, tk_rm = 0, tk_vm = 0;
+    [[maybe_unused]] int tw_tok = 0, tw_rm = 0, tw_vm = 0;         // SPLIT: the WINDOW's column tid0 (the agreement predicates look at all of it)
     auto cst_request = [&](int l, int tid) { if (tid < 128) creq = *(const v4f*)((const float*)(blk_of(l) + WX_CST_OFF) + tid * 4); };
     auto first_request = [&](int tid) {                          // the segment's first layer, for the next row
         cst_request(a.l_begin, tid);
         load_first(pre_a, (gbf8)(blk_of(a.l_begin) + WX_CONV_OFF) + 4 * q * 64 + (tid & 63));
     };
-    auto token_request = [&](int row_index, int tid) {           // one window column per thread (L <= 208 < 512)
+    auto token_request = [&](int row_index, int u_off, int tid) {  // one column per thread (L <= 208, Lw <= 304 < 512)
+        const size_t rb0 = (size_t)row_index * Lw, sb0 = (size_t)(row_index / a.R) * Lw;
         if (tid < L) {
-            const size_t rb = (size_t)row_index * L + tid, sbs = (size_t)(row_index / a.R) * L + tid;
+            const size_t rb = rb0 + u_off + tid, sbs = sb0 + u_off + tid;
             tk_tok = a.reads[rb]; tk_q = a.qual[rb]; tk_st = a.strand[rb];
             tk_rf = a.ref[sbs]; tk_rm = a.ref_mask[sbs]; tk_vm = a.var_mask[sbs];
+        }
+        if constexpr (SPLIT) {
+            tw_tok = tw_rm = tw_vm = 0;
+            if (tid < Lw) { tw_tok = a.reads[rb0 + tid]; tw_rm = a.ref_mask[sb0 + tid]; tw_vm = a.var_mask[sb0 + tid]; }
         }
     };
     {
         const int r0 = __builtin_amdgcn_readfirstlane(row_of(jw));
         if (r0 >= 0) {
+            const XUnit u0 = unit_of(jw);
             first_request(tid0);
             if (resumed) {
-                dma_read(r0, tid0 & 63);
-                if (a.pool) seed_request(r0, tid0 & 63);
+                dma_read(r0, u0.off, tid0 & 63);
+                if (a.pool) seed_request(r0, u0.off, tid0 & 63);
             } else {
-                token_request(r0, tid0);
+                token_request(r0, u0.off, tid0);
             }
         }
     }
@@ -318,6 +341,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
         const int row_index = __builtin_amdgcn_readfirstlane(row_of(k));
         if (row_index < 0) break;
         const int next_row = __builtin_amdgcn_readfirstlane(row_of(k + nj));
+        const XUnit cu = unit_of(k), nu = unit_of(k + nj);         // this work item's unit and the next one's
         // (an opaque copy of the thread index per row: hipcc otherwise forms every per-lane address of the row body ahead of the
         // row loop and keeps them -- spilled -- through all of it)
         int tid = tid0;
@@ -334,7 +358,11 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // ---- encode (dl4vc/model.py:450-627), canonical 48-channel order, split into the two planes; thread p = column p
             const int tok = tk_tok, qv = tk_q, st = tk_st, rf = tk_rf, rm = tk_rm, vm = tk_vm;
             const bool col = tid < L;
-            const int ok_ref = !col || (rm == 0) || (tok == rm), ok_var = !col || (vm == 0) || (tok == vm);
+            int ok_ref = !col || (rm == 0) || (tok == rm), ok_var = !col || (vm == 0) || (tok == vm);
+            if constexpr (SPLIT) {                               // ... over the whole window, not the unit
+                ok_ref = (tw_rm == 0) || (tw_tok == tw_rm);
+                ok_var = (tw_vm == 0) || (tw_tok == tw_vm);
+            }
             // workgroup-wide AND through sixteen flag words in the constants buffer that is not in use at a row's start
             int* flags = (int*)cbuf(a.l_begin + 1);
             {
@@ -349,7 +377,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 const int p = tid;
                 const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
                 const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
-                const float* pp = a.pe + p * EMBED;
+                const float* pp = a.pe + (cu.off + p) * EMBED;
                 float row[64];
 #pragma unroll
                 for (int e = 0; e < EMBED; ++e) { const float pv = pp[e]; row[e] = er[e] + pv; row[EMBED + e] = ef[e] + pv; }
@@ -377,16 +405,16 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
         if (resumed) {
             // this wave's pieces of the DMA'd image have landed.  Behind them in the queue are only the previous row's copy-out stores
             // (at least L / 16 per wave): they may stay in flight
-            if (L >= 192) __builtin_amdgcn_s_waitcnt(0x0F70 | 12);   // vmcnt(12)
-            else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+            if (!SPLIT && L >= 192) __builtin_amdgcn_s_waitcnt(0x0F70 | 12);   // vmcnt(12)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)  (a split unit stores fewer than twelve chunks per thread)
         }
         __syncthreads();
         XSTAMP(1);
 
         auto copy_tap = [&](int nch) {
             // image -> fp32 [L][CPAD] (debug tap)
-            float* dst = a.tap + read_idx * (size_t)L * CPAD;
-            for (int i = tid; i < L * (CPAD / 8); i += SEG_THREADS) {
+            float* dst = a.tap + (read_idx * (size_t)Lw + cu.off) * CPAD;
+            for (int i = cu.lo * (CPAD / 8) + tid; i < cu.hi * (CPAD / 8); i += SEG_THREADS) {
                 const int p = i >> 4, c = i & 15;
                 const bf8 vh = lds_read(lds, cell_addr(P_HALO + p, c)), vl = lds_read(lds + X_LO, cell_addr(P_HALO + p, c));
                 v4f o0, o1;
@@ -430,7 +458,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // 4.7 k cycles under the stamps, but the 64 registers beside the live accumulators spilled 76 and the bench lost 10 %.)
             if (defer)
                 bottleneck_x<NWAVE / 2>(lds, (gbf8)(blk_of(l - 1) + WX_BOT_OFF) + lane, (const float*)(blk_of(l - 1) + WX_CST_OFF) + CST_BBOT,
-                                        a.h + (size_t)(l - 1) * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+                                        a.h + (size_t)(l - 1) * a.h_layer_stride + (read_idx * (size_t)Lw + cu.off) * HPAD, L, wave, lane, cu.lo, cu.hi);
             XFENCE();
             XSTAMP(sb + 7);
             // ---- epilogue: ReLU, BatchNorm (folded), columns past the window forced to zero, split; the packed outputs wait in
@@ -529,8 +557,10 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 int t2 = tid, nr = next_row;
                 asm volatile("" : "+v"(t2), "+s"(nr));
                 first_request(t2);
-                if (resumed) { if (a.pool) seed_request(nr, t2 & 63); }
-                else token_request(nr, t2);
+                int noff = nu.off;
+                asm volatile("" : "+s"(noff));
+                if (resumed) { if (a.pool) seed_request(nr, noff, t2 & 63); }
+                else token_request(nr, noff, t2);
             }
             __syncthreads();
             XFENCE();
@@ -538,7 +568,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             if (a.tap && a.tap_layer == l + 1) copy_tap(CPAD);
             if (a.has_hw && last_layer)
                 bottleneck_x<NWAVE>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
-                                    a.h + (size_t)l * a.h_layer_stride + read_idx * (size_t)L * HPAD, L, wave, lane);
+                                    a.h + (size_t)l * a.h_layer_stride + (read_idx * (size_t)Lw + cu.off) * HPAD, L, wave, lane, cu.lo, cu.hi);
             XSTAMP(sb + 6);
         }
         XSTAMP(62);
@@ -550,9 +580,9 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // (chunk ^ row) & 15 does not change with k2, so the LDS address is ONE base + k2 * 16 KiB (immediate offsets) and the
             // destination one base + k2 * 8 KiB.  (As one flat walk over both planes, with the plane and a clamp derived per element,
             // the 13 reads cost 179 vector instructions of address arithmetic per row.)
-            char* ydst = (char*)(a.y + read_idx * y_row);
+            char* ydst = (char*)((SPLIT ? a.y_out : a.y) + read_idx * y_row) + (size_t)cu.off * P_ROW_BYTES;
             constexpr int NCP = (X_LMAX * (CPAD / 8) + SEG_THREADS - 1) / SEG_THREADS;        // 7 sweeps per plane
-            const int n8 = L * (CPAD / 8);
+            const int n8 = Lw * (CPAD / 8);                          // chunks of one plane of the window
             const unsigned src0 = cell_addr(P_HALO + (tid >> 4), tid & 15);
             bf8 v[2][NCP];
 #pragma unroll
@@ -561,13 +591,13 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
                 for (int k2 = 0; k2 < NCP; ++k2)
                     v[pl][k2] = lds_read(lds + pl * X_LO + k2 * (32 * X_ROW_BYTES), src0);       // (rows past the window: zeros or stale, never stored)
             __syncthreads();                                     // every read of the image is done: the next row may land in it
-            if (resumed && next_row >= 0) dma_read(next_row, lane);
+            if (resumed && next_row >= 0) dma_read(next_row, nu.off, lane);
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                 for (int k2 = 0; k2 < NCP; ++k2) {
-                    const int i = tid + k2 * SEG_THREADS;
-                    if (i < n8) *(bf8*)(ydst + (size_t)(unsigned)((pl * n8 + i) * 16)) = v[pl][k2];
+                    const int i = tid + k2 * SEG_THREADS;              // chunk i of the unit = column i >> 4
+                    if (i >= cu.lo * (CPAD / 8) && i < cu.hi * (CPAD / 8)) *(bf8*)(ydst + (size_t)(unsigned)((pl * n8 + i) * 16)) = v[pl][k2];
                 }
         }
         XSTAMP(63);
@@ -580,13 +610,16 @@ void launch_segmentx(const SegmentXArgs& a0, int n_sites, int n_cus, hipStream_t
     SegmentXArgs a = a0;
     a.n_rows = n_sites * a.R;
     a.slice_rows = (n_sites + 7) / 8 * a.R;
+    const bool split = a.units == 2;
+    if (!split) { a.units = 1; a.Lw = a.L; a.y_out = a.y; }       // (callers that never heard of units: one unit, the whole window, in place)
     int wgs = n_cus > 0 ? n_cus : 256;
     wgs = (wgs + 7) / 8 * 8;
-    const int need = (a.slice_rows < 1 ? 1 : a.slice_rows) * 8;   // no more workgroups than rows per slice x 8
+    const int need = (a.slice_rows < 1 ? 1 : a.slice_rows) * 8 * (split ? 2 : 1);   // no more workgroups than work items per slice x 8
     if (wgs > need) wgs = need;
     // one row takes ~30 us (layers 1-2) / ~100 us (layers 3-7): the offsets spread the workgroups over about one row
     if (a.stagger < 0) a.stagger = (a.l_end - a.l_begin) <= 2 ? 1 : 3;
-    hipLaunchKernelGGL(x3::segmentx_kernel, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    if (split) hipLaunchKernelGGL(x3::segmentx_kernel<true>, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(x3::segmentx_kernel<false>, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,9 +1,10 @@
-"""fp32 parity path for windows of 209..304 columns (VERDICT r4 "missing" 5; SURVEY.md section 8a: R and L are configuration;
+"""Parity paths (fp32 and, since the same round, bf16x3) for windows of 209..304 columns (VERDICT r4 "missing" 5; SURVEY.md section 8a: R and L are configuration;
 reference: dl4vc/model.py:41 single_read_len, :214-231).  A read above 208 columns does not fit the LDS image of the fp32 segment
 kernel, so it is computed as TWO overlapping units (csrc/dan_kernels.h plan_units, segment_kernel<., ., SPLIT = true>): each unit
 is an ordinary <= 208-column read of the kernel, the overlap is the segment's receptive-field radius, a unit stores only its own
 columns, y crosses segments out of place.  Held to the reference's own fp32 outputs (tests/golden/long_*.npz) and to the oracle
-at the fp32 path's bars.  GPU only."""
+at the fp32 path's bars.  The bf16x3 kernel (csrc/dan_kernels_bf16x.hip, segmentx_kernel<SPLIT = true>) takes the same unit plan:
+the same fixtures and structures at the bars of tests/test_hip_bf16.py.  GPU only."""
 import dataclasses
 
 import numpy as np
@@ -56,6 +57,41 @@ def test_long_window_golden_outputs_and_taps(case, algo):
     net.close()
 
 
+@pytest.mark.parametrize("case", long_cases())
+def test_long_window_golden_outputs_and_taps_bf16x3(case):
+    """The same two reference runs on the split-bf16 kernel (precision 1): scores 1e-4 absolute, the six heads, the feature row, the
+    hidden layer and the conv2 / conv7 taps within 1e-4 of the tensor's magnitude -- the bars the 201-column fixtures are held to."""
+    spec, w, inp, out = load_case(case)
+    cfg = cfg_from(spec, precision=PRECISION_BF16X3)
+    net = DanNet(cfg).load_state_dict(w)
+    assert net.handle.query("bf16x3_split_kernel") == 1
+    got = net.forward_u8(*input_tuple(inp), aux=True)
+    errs = {}
+    for k in ("vt_prob", "bp"):
+        errs[k] = float(np.abs(got[k] - out[k]).max())
+        close(got[k], out[k], SCORE_ATOL, "%s:%s" % (case, k))
+    for k in ("bin_logits", "vt_logits", "af", "cov", "vb", "vr"):
+        errs[k] = float(np.abs(got[k] - out[k]).max()) / max(1.0, float(np.abs(out[k]).max()))
+        close(got[k], out[k], TAP_RTOL, "%s:%s" % (case, k))
+    F, Fs = net.handle.query("feature_width"), net.handle.query("feature_stride")
+    B, R, L = inp["reads"].shape
+    feat = net.handle.read_buffer("feature", B * Fs).reshape(B, Fs)[:, :F]
+    close(feat, out["feature"], TAP_RTOL, case + ":feature")
+    hid = net.handle.read_buffer("hidden1", B * cfg.fc_sizes[1]).reshape(B, -1)
+    close(hid, out["hidden"], TAP_RTOL, case + ":hidden")
+    cpad = net.handle.query("cpad")
+    for layer in (2, 7):
+        net.handle.set_tap(layer)
+        net.forward_u8(*input_tuple(inp))
+        tap = net.handle.read_buffer("tap", B * R * L * cpad).reshape(B, R, L, cpad)
+        ref = out["conv%d" % layer]
+        g = np.transpose(tap[:ref.shape[0], :, :, :ref.shape[1]], (0, 3, 1, 2))
+        close(g, ref, TAP_RTOL, "%s:conv%d" % (case, layer))
+        assert np.all(tap[..., ref.shape[1]:] == 0), "pad channels must stay zero"
+    print("bf16x3 %s: " % case + " ".join("%s %.2g" % kv for kv in errs.items()))
+    net.close()
+
+
 LONG_STRUCTURES = {
     # (reads, length, layers, pools, residual_start, c_init, c_final, bottleneck, extra)
     "l240_pools_1_3": dict(reads=9, length=240, layers=5, pool_layers=(1, 3), residual_start=4, c_init=48, c_final=128, bottleneck=8),
@@ -91,6 +127,22 @@ def test_long_window_structures_all_forms_agree(name):
     for k in outs["auto"]:
         assert np.array_equal(outs["auto"][k], outs["skip"][k]), (name, "skip", k)
         assert np.array_equal(outs["auto"][k], outs["chunks"][k]), (name, "chunks", k)
+    # ... and on the bf16x3 kernel: the oracle at the same bars (the score bar grows with the logits' magnitude above 16, the stated
+    # limit of a two-piece operand: tests/test_hip_parity.py::test_random_structures_bf16x3), skip / chunks bit-identical
+    cx = dataclasses.replace(cfg, precision=PRECISION_BF16X3)
+    mag = max(float(np.abs(want["vt_logits"]).max()), float(np.abs(want["bin_logits"]).max()))
+    bar = SCORE_ATOL * max(1.0, mag / 16.0)
+    xo = {}
+    for tag, c, kwn in (("x3", cx, {}), ("x3 skip", dataclasses.replace(cx, skip_empty_rows=True), {}), ("x3 chunks", cx, dict(chunk_sites=2, max_batch=4))):
+        net = DanNet(c, **kwn).load_state_dict(sd)
+        xo[tag] = got = net.forward_u8(*batch.arrays(), aux=True)
+        net.close()
+        for k in ("vt_prob", "bp"):
+            close(got[k], want[k], bar, "%s %s %s" % (name, tag, k))
+        close(got["vt_logits"], want["vt_logits"], TAP_RTOL, "%s %s vt_logits" % (name, tag))
+    for k in xo["x3"]:
+        assert np.array_equal(xo["x3"][k], xo["x3 skip"][k]), (name, "x3 skip", k)
+        assert np.array_equal(xo["x3"][k], xo["x3 chunks"][k]), (name, "x3 chunks", k)
 
 
 def test_config5_shape_in_fp32():
@@ -114,21 +166,28 @@ def test_config5_shape_in_fp32():
         close(got[k], want[k], SCORE_ATOL, k)
     close(got["vt_logits"], want["vt_logits"], TAP_RTOL, "vt_logits")
     print("128 x 301 fp32: max |vt_prob - oracle| %.3g" % float(np.abs(got["vt_prob"] - want["vt_prob"]).max()))
+    net = DanNet(dataclasses.replace(cfg, precision=PRECISION_BF16X3)).load_state_dict(sd)
+    gx = net.forward_u8(*arrs, aux=True)
+    net.close()
+    for k in ("vt_prob", "bp"):
+        close(gx[k], want[k], SCORE_ATOL, "bf16x3 " + k)
+    close(gx["vt_logits"], want["vt_logits"], TAP_RTOL, "bf16x3 vt_logits")
+    print("128 x 301 bf16x3: max |vt_prob - oracle| %.3g" % float(np.abs(gx["vt_prob"] - want["vt_prob"]).max()))
 
 
 def test_window_limits_per_precision():
-    """fp32 takes windows up to 304 columns now (two units per read); bf16x3 stays at 208 (one image, two planes), plain bf16 at
-    304; 305 is refused everywhere, and so is a long window whose segment reaches further sideways than half an image has room for
-    (sixteen unpooled layers at dilation 4: 61 columns + 152 > 208) -- with the reason in the message."""
+    """fp32 and bf16x3 take windows up to 304 columns (two units per read), plain bf16 as well (its two images hold 304); 305 is
+    refused everywhere, and so is -- at precisions 0 and 1 -- a long window whose segment reaches further sideways than half an
+    image has room for (sixteen unpooled layers at dilation 4: 61 columns + 152 > 208), with the reason in the message."""
     DanNet(DanConfig(reads=8, length=301)).close()
     DanNet(DanConfig(reads=8, length=304, precision=PRECISION_BF16)).close()
-    with pytest.raises(RuntimeError, match="length"):
-        DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16X3))
+    DanNet(DanConfig(reads=8, length=301, precision=PRECISION_BF16X3)).close()
     for prec in (0, PRECISION_BF16X3, PRECISION_BF16):
         with pytest.raises(RuntimeError, match="length"):
             DanNet(DanConfig(reads=8, length=305, precision=prec))
     deep = dict(reads=4, layers=16, pool_layers=(), residual_start=0, dil_mid=4, dil_final=4, c_init=16, c_final=16, bottleneck=4, fc_sizes=(16, 8))
-    with pytest.raises(RuntimeError, match="sideways"):
-        DanNet(DanConfig(length=304, **deep))
+    for prec in (0, PRECISION_BF16X3):
+        with pytest.raises(RuntimeError, match="sideways"):
+            DanNet(DanConfig(length=304, precision=prec, **deep))
     DanNet(DanConfig(length=208, **deep)).close()              # the same network on one unit is fine
     DanNet(DanConfig(length=280, **deep)).close()              # 140 + 61 <= 208
