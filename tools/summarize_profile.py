@@ -220,7 +220,7 @@ def extras(tag, dst):
                 t, b = traffic.get(sec), rec.get("build", {})
                 return bool(t) and t.get("source_hash") == b.get("source_hash") and t.get("chunk_sites") in (None, b.get("chunk_sites"))
             for b_, sec, key in (("train", "train_step_b64", "hbm_bytes_per_step"), ("train_b10", "train_step_b10", "hbm_bytes_per_step"),
-                                 ("bf16x3", "segmentx_kernel_bytes_per_launch", "total"), ("bf16_128x301", "segmentp_kernel_bytes_per_launch", "total")):
+                                      ("bf16x3", "segmentx_kernel_bytes_per_launch", "total"), ("bf16_128x301", "segmentp_kernel_bytes_per_launch", "total")):
                 if base == b_ and same(sec):
                     rec["roofline"]["traffic"] = int(traffic[sec][key])
                     rec["roofline"]["traffic_stale"] = False
