@@ -932,16 +932,18 @@ int dan_forward_async(dan_t* h, const uint8_t* reads, const uint8_t* qual, const
                     pieces.push_back({sl.pin_in + o + a0, src[i] + s0 * per_site[i] + a0, a1 - a0});
                 }
             }
-            if (n_thr == 1) {
-                for (auto& pc : pieces) memcpy(pc.dst, pc.src, pc.n);
-            } else {
-                std::vector<std::thread> pool;
-                for (int t = 1; t < n_thr; ++t)
+            // (a thread that cannot be started -- std::system_error -- must not leave through the C ABI: its pieces are copied here)
+            std::vector<std::thread> pool;
+            std::vector<char> started((size_t)n_thr, 0);
+            for (int t = 1; t < n_thr; ++t) {
+                try {
                     pool.emplace_back([&pieces, t, n_thr] { for (size_t j = t; j < 3 * (size_t)n_thr; j += n_thr) memcpy(pieces[j].dst, pieces[j].src, pieces[j].n); });
-                for (size_t j = 0; j < pieces.size(); ++j)
-                    if (j >= 3 * (size_t)n_thr || j % n_thr == 0) memcpy(pieces[j].dst, pieces[j].src, pieces[j].n);
-                for (auto& th : pool) th.join();
+                    started[t] = 1;
+                } catch (...) {}
             }
+            for (size_t j = 0; j < pieces.size(); ++j)
+                if (j >= 3 * (size_t)n_thr || !started[j % n_thr]) memcpy(pieces[j].dst, pieces[j].src, pieces[j].n);
+            for (auto& th : pool) th.join();
             for (int i = 0; i < 6; ++i) {
                 const size_t o = off[i] + s0 * per_site[i];
                 HIPCHK(h, hipMemcpyAsync(sl.dev_in + o, sl.pin_in + o, ns * per_site[i], hipMemcpyHostToDevice, h->s_h2d));
