@@ -62,6 +62,7 @@ struct dan_handle {
     char* d_wlx = nullptr;                   // [layers][WX_LAYER_BYTES] hi / lo 16x16x32 fragments of the bf16x3 kernel
     unsigned res_mask = 0;
     float *d_emb = nullptr, *d_pe = nullptr;
+    float* d_l0tab = nullptr;                // fp32 path: layer 1 by table (dan_kernels.h L0_*)
     float *d_y = nullptr, *d_pool = nullptr, *d_h = nullptr, *d_tap = nullptr;
     float* d_y2 = nullptr;                   // fp32 windows above MPOS columns (two units per read): the segments' y alternates between d_y and d_y2
     bool split = false;
@@ -463,6 +464,40 @@ int dan_finalize(dan_t* h) {
         };
         std::vector<float> packed = pack_frag(3, kg, KGC, Wf);
         std::copy(packed.begin(), packed.end(), blk + W_OFF);
+        if (l == 0 && c.precision == 0) {
+            // layer 1 by table (dan_kernels.h L0_*): conv1 is linear in the terms its input column is a sum of; sums in double
+            std::vector<float> tab(l0_tab_floats(L), 0.f);
+            for (int t = 0; t < 3; ++t)
+                for (int o = 0; o < CPAD; ++o) {
+                    for (int ta = 0; ta < VOCAB; ++ta)
+                        for (int tb = 0; tb < VOCAB; ++tb) {
+                            double v = 0.0;
+                            for (int e = 0; e < EMBED; ++e)
+                                v += (double)Wf(o, e, t) * emb->data[(size_t)ta * EMBED + e] + (double)Wf(o, EMBED + e, t) * emb->data[(size_t)tb * EMBED + e];
+                            tab[L0_TJ_OFF + ((size_t)t * L0_NTJ + ta * 10 + tb) * CPAD + o] = (float)v;
+                        }
+                    for (int k = 0; k < 5; ++k) tab[L0_WSC_OFF + ((size_t)k * 3 + t) * CPAD + o] = Wf(o, 2 * EMBED + k, t);
+                }
+            // the positional term of tap t at column w: sum_e (W[o][e][t] + W[o][20 + e][t]) pe[w][e]; PE[variant][w] = the taps whose
+            // column w + t - 1 exists for a unit that has / lacks a left / right neighbour at w (and lies inside the window anyway)
+            std::vector<double> pet((size_t)3 * L * CPAD);
+            for (int t = 0; t < 3; ++t)
+                for (int wcol = 0; wcol < L; ++wcol)
+                    for (int o = 0; o < CPAD; ++o) {
+                        double v = 0.0;
+                        for (int e = 0; e < EMBED; ++e) v += ((double)Wf(o, e, t) + (double)Wf(o, EMBED + e, t)) * pe->data[(size_t)wcol * EMBED + e];
+                        pet[((size_t)t * L + wcol) * CPAD + o] = v;
+                    }
+            for (int var = 0; var < 3; ++var)
+                for (int wcol = 0; wcol < L; ++wcol)
+                    for (int o = 0; o < CPAD; ++o) {
+                        double v = pet[((size_t)1 * L + wcol) * CPAD + o];
+                        if (var != 1 && wcol - 1 >= 0) v += pet[((size_t)0 * L + wcol - 1) * CPAD + o];
+                        if (var != 2 && wcol + 1 < L) v += pet[((size_t)2 * L + wcol + 1) * CPAD + o];
+                        tab[L0_PE_OFF + ((size_t)var * L + wcol) * CPAD + o] = (float)v;
+                    }
+            if ((rc = dev_upload(h, &h->d_l0tab, tab))) return rc;
+        }
         if (l > 0) {
             // Winograd F(2,3) weight transform U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2], formed in double
             auto Wu = [&](int o, int cc, int k) -> float {
@@ -746,6 +781,7 @@ static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qu
                 a.tap = tap_here ? h->d_tap : nullptr;
                 a.tap_layer = h->tap_layer;
                 a.wino = h->wino;
+                a.l0_tab = h->d_l0tab;
                 a.work = h->d_work; a.work_count = h->d_rowsrc ? h->d_work_count : nullptr;
                 EventPair ev{};
                 int rc = prof_begin(h, "conv_segment", s, &ev); if (rc) return rc;

@@ -69,6 +69,8 @@ struct SegmentArgs {
     int xcd_rows;                // filled by launch_segment: rows per XCD slice (whole sites)
     const int* work;             // rows to compute (device list, see launch_row_map); read only when work_count is set
     const int* work_count;       // length of that list (device) or nullptr = every row
+    // ---- (may be null) layer 1 by table instead of encode + GEMM (L0_* below; built by dan_finalize)
+    const float* l0_tab;
     // ---- windows of 209..304 columns (units == 2; plan_units fills these): a read no longer fits the 208-row LDS image, so it
     // is computed as TWO overlapping units, each an ordinary <= 208-column "read" of the kernel: unit u covers window columns
     // [u_off, u_off + u_len) and STORES (y, h, tap) only its own columns [own_lo, own_hi) (unit-relative).  The overlap is the
@@ -85,6 +87,24 @@ struct SegmentArgs {
 // receptive-field radius.  Returns false when a unit would not fit (window > 2 (MPOS - halo)).  For Lw <= MPOS: one unit, the whole
 // window.  Both units have the SAME length (for an odd window the second starts one column earlier): the bf16x3 kernel keeps its
 // image across rows and relies on the rows past a unit's length staying zero.
+// Layer 1 by table (fp32 path).  The network's first conv sees an input that is a SUM of per-column terms -- embedding of the read
+// token + positional encoding, embedding of the reference token + the same encoding, q, strand and three mask flags (model.py:
+// 450-627) -- so conv1 is linear in each of them: out[p] = bias + sum over taps t of
+//     TJ[t][10 tok + ref][.]  +  PE_t[p + t - 1][.]  +  q W_q[t] + strand W_s[t] + m1 W_1[t] + m2 W_2[t] + m3 W_3[t]      (column p + t - 1)
+// with columns outside the unit contributing nothing (the conv's zero padding).  ~50 packed vector instructions per four outputs
+// instead of building 48 channels per column and a K = 144 GEMM on the matrix cores (4.3 % of the network's MACs, a fifth of the
+// first segment's time).  l0_tab (floats): TJ [tap 3][read token x ref token 100, + one all-zero entry][CPAD] | W_sc [channel 5: q,
+// strand, refmatch, varmatch, lenmask][tap 3][CPAD] | PE [variant 3: both neighbours, no left neighbour, no right neighbour][window
+// column Lw][CPAD] (the positional term of all valid taps, summed on the host in double).  The walk is branch-free: the columns either
+// side of the unit are staged as the all-zero table entry with zero scalars.
+constexpr int L0_NTJ = 101;                                  // entries of TJ per tap (index 100 = zeros)
+constexpr int L0_TJ_OFF = 0;
+constexpr int L0_WSC_OFF = L0_TJ_OFF + 3 * L0_NTJ * CPAD;    // 38 784
+constexpr int L0_PE_OFF = L0_WSC_OFF + 5 * 3 * CPAD;         // 40 704
+inline size_t l0_tab_floats(int Lw) { return (size_t)L0_PE_OFF + (size_t)3 * Lw * CPAD; }
+constexpr int L0_TOK = 8;                                    // floats per staged column: table index, q 0.01, strand 0.5, lenmask flag, varmatch flag (entry 0: [5] = the read agrees with the reference allele)
+constexpr int L0_MAX_LAYERS = (MAX_LAYERS * CST_FLOATS - (MPOS + 2) * L0_TOK) / CST_FLOATS;   // they live behind the segment's constants: 12 layers leave room
+
 template <class Args>
 inline bool plan_units(Args& a, int Lw, int halo) {
     a.Lw = Lw;

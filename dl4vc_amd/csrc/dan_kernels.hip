@@ -166,7 +166,10 @@ next_row:                                                   // (PERSIST only: ba
             f0 = w0[0]; f1 = w0[64];
         }
     };
-    if (!WINO || a.l_begin == 0) first_frags(a.l_begin, pc0, pc1, pc2, pc3);
+    // layer 1 by table (dan_kernels.h L0_*): no encoded image, no GEMM -- unless the tap asks for the encoded input itself
+    const bool l0_lookup = a.l_begin == 0 && a.l0_tab != nullptr && !(a.tap && a.tap_layer == 0) && (a.l_end - a.l_begin) <= L0_MAX_LAYERS;
+    float* const tokf = cst + (a.l_end - a.l_begin) * CST_FLOATS;           // [L + 2][L0_TOK] (column p at entry p + 1), behind the segment's constants
+    if ((!WINO || a.l_begin == 0) && !l0_lookup) first_frags(a.l_begin, pc0, pc1, pc2, pc3);
     auto stage_constants = [&]() {
         for (int i = tid; i < (a.l_end - a.l_begin) * CST_FLOATS; i += SEG_THREADS) {
             const int l = i / CST_FLOATS, j = i - l * CST_FLOATS;
@@ -175,7 +178,15 @@ next_row:                                                   // (PERSIST only: ba
     };
 
     if (a.l_begin == 0) {
-        for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+        if (l0_lookup) {                                     // (every row of the window is written by the table walk: only the others are cleared)
+            for (int i = tid; i < (LDS_ROWS - L) * (LDS_S / 4); i += SEG_THREADS) {
+                const int rr = i / (LDS_S / 4), c4 = i - rr * (LDS_S / 4);
+                const int row = rr < HALO ? rr : rr + L;
+                *(v4f*)(xs + row * LDS_S + c4 * 4) = splat(0.f);
+            }
+        } else {
+            for (int i = tid; i < LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
+        }
         stage_constants();
         __syncthreads();
         // ---- encode (dl4vc/model.py:450-627): canonical 48-channel order
@@ -197,7 +208,24 @@ next_row:                                                   // (PERSIST only: ba
         }
         const int agree_ref = __syncthreads_and((rm_w == 0) || (tok_w == rm_w));
         const int agree_var = __syncthreads_and((vm_w == 0) || (tok_w == vm_w));
-        if (in) {
+        if (l0_lookup) {
+            // the column's table index and scalar channels; the columns either side of the unit: the all-zero table entry, zero scalars
+            // (entry 0 also carries the read's agreement with the reference allele: refmatch = agreement x lenmask, one weight per read)
+            if (p <= L + 1) {
+                const int pc = p - 1;                            // thread e stages column e - 1
+                int tk = 0, qq = 0, ss = 0, rr = 0, mm = 0, vv = 0;
+                const bool inside = pc >= 0 && pc < L;
+                if (inside) {
+                    tk = a.reads[rbase + pc]; qq = a.qual[rbase + pc]; ss = a.strand[rbase + pc];
+                    rr = a.ref[sbase + pc]; mm = a.ref_mask[sbase + pc]; vv = a.var_mask[sbase + pc];
+                }
+                float* t = tokf + p * L0_TOK;
+                const v4f t0 = {__builtin_bit_cast(float, inside ? min(tk, VOCAB - 1) * 10 + min(rr, VOCAB - 1) : 100), (float)qq * 0.01f, (float)ss * 0.5f,
+                                (inside && mm != 0) ? 1.f : 0.f};
+                const v4f t1 = {(inside && vv != 0 && agree_var) ? 1.f : 0.f, (p == 0 && agree_ref) ? 1.f : 0.f, 0.f, 0.f};
+                *(v4f*)t = t0; *(v4f*)(t + 4) = t1;
+            }
+        } else if (in) {
             float* row = xs + (HALO + p) * LDS_S;
             const float* er = a.emb + min(tok, VOCAB - 1) * EMBED;
             const float* ef = a.emb + min(rf, VOCAB - 1) * EMBED;
@@ -519,13 +547,79 @@ next_row:                                                   // (PERSIST only: ba
         }
     };
 
+    // ---- layer 1 by table (dan_kernels.h L0_*): thread = (four channels c4, position p = pr + 16 k); the image rows are written directly
+    auto lookup_layer0 = [&]() {
+        const float* lc = cst;
+        [[maybe_unused]] const int sb = 2;
+        if (!WINO && 1 < a.l_end) first_frags(1, pn0, pn1, pn2, pn3);
+        STAMP(sb + 0);
+        const int c4 = tid & 31, pr = tid >> 5;
+        const v4f bias = *(const v4f*)(lc + CST_BIAS + c4 * 4), sc = *(const v4f*)(lc + CST_SCALE + c4 * 4), sh = *(const v4f*)(lc + CST_SHIFT + c4 * 4);
+        // per tap: q, strand, lenmask (+ refmatch where the read agrees with the reference allele: one combined weight), varmatch
+        v4f wq[3], wst[3], wlen[3], wvar[3];
+        {
+            const float agree = tokf[5];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                auto wv = [&](int k) { return *(const v4f*)(a.l0_tab + L0_WSC_OFF + (k * 3 + t) * CPAD + c4 * 4); };
+                wq[t] = wv(0); wst[t] = wv(1); wvar[t] = wv(3);
+                wlen[t] = wv(4) + agree * wv(2);
+            }
+        }
+        const v4f* tj = (const v4f*)(a.l0_tab + L0_TJ_OFF) + c4;
+        const v4f* pe = (const v4f*)(a.l0_tab + L0_PE_OFF) + (size_t)u_off * (CPAD / 4) + c4;
+#pragma unroll 4
+        for (int k = 0; k < MT; ++k) {
+            const int p = min(pr + 16 * k, L - 1);                   // (clamped: the last sweep's extra threads recompute column L - 1)
+            const int var = (p == 0) ? 1 : (p == L - 1) ? 2 : 0;         // which neighbours the unit has at this column
+            const v4f pe0 = pe[((size_t)var * Lw + p) * (CPAD / 4)];
+            v4f s0[3], tv[3];
+            v2f s1[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                s0[t] = *(const v4f*)(tokf + (p + t) * L0_TOK);          // column p + t - 1 at entry p + t
+                s1[t] = *(const v2f*)(tokf + (p + t) * L0_TOK + 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) tv[t] = tj[(size_t)(t * L0_NTJ + __builtin_bit_cast(int, s0[t][0])) * (CPAD / 4)];
+            v2f alo = {bias[0] + pe0[0], bias[1] + pe0[1]}, ahi = {bias[2] + pe0[2], bias[3] + pe0[3]};   // (packed fp32: two lanes per instruction)
+            auto fma4 = [&](float sv, const v4f& w) {
+                const v2f ss = {sv, sv};
+                alo = __builtin_elementwise_fma(ss, (v2f){w[0], w[1]}, alo);
+                ahi = __builtin_elementwise_fma(ss, (v2f){w[2], w[3]}, ahi);
+            };
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                alo += (v2f){tv[t][0], tv[t][1]}; ahi += (v2f){tv[t][2], tv[t][3]};
+                fma4(s0[t][1], wq[t]);
+                fma4(s0[t][2], wst[t]);
+                fma4(s0[t][3], wlen[t]);
+                fma4(s1[t][0], wvar[t]);
+            }
+            v4f v;
+            v[0] = relu1(alo[0]) * sc[0] + sh[0]; v[1] = relu1(alo[1]) * sc[1] + sh[1];
+            v[2] = relu1(ahi[0]) * sc[2] + sh[2]; v[3] = relu1(ahi[1]) * sc[3] + sh[3];
+            *(v4f*)(xs + (HALO + p) * LDS_S + c4 * 4) = v;
+        }
+        STAMP(sb + 2);
+        const bool bot_here = a.has_hw && !(WINO && 1 < a.l_end);
+        if (bot_here) {
+            gv4f_ptr w_bot = (gv4f_ptr)(a.wl + WBOT_OFF) + lane;
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) wbot[g] = w_bot[(g * 2 + (wave & 1)) * 64];
+        }
+        layer_tail(0, lc, true);
+    };
+
     if constexpr (WINO) {
         // host contract (launch_segment): every layer after the network's first has dilation 2
         int l = a.l_begin;
-        if (l == 0) { direct_layer(0); l = 1; }
+        if (l == 0) { if (l0_lookup) lookup_layer0(); else direct_layer(0); l = 1; }
         for (; l < a.l_end; ++l) wino_layer_body(l);
     } else {
-        for (int l = a.l_begin; l < a.l_end; ++l) direct_layer(l);
+        int l = a.l_begin;
+        if (l == 0 && l0_lookup) { lookup_layer0(); l = 1; }
+        for (; l < a.l_end; ++l) direct_layer(l);
     }
     STAMP(62);
     copy_out(xs, yout, own_lo, own_hi, tid);
