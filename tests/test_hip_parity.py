@@ -75,6 +75,46 @@ def test_golden_layer_taps(layer, algo):
     net.close()
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("case", ["dan_small", "dan_var_noqs", "dan_var_nomask", "dan_var_nobn", "dan_var_pool24"])
+def test_layer1_by_table_matches_the_encoded_gemm(case, algo):
+    """Round 5: the fp32 path computes layer 1 from tables (dan_kernels.h L0_*) instead of encoding 48 channels per column and
+    running a K = 144 GEMM.  A tap on the encoded input (layer 0) keeps the OLD path for that forward: both forms of layer 1 must give
+    the same network -- scores and logits of the same sites to 1e-5 of their magnitude (both are held to the reference's outputs by
+    the golden tests; this one compares them with each other, channel flags on and off, with and without pool layers) -- and the
+    layer-1 activations themselves, which the table form exports through the layer-1 tap, must match an fp64 evaluation of conv1."""
+    import torch
+    spec, w, inp, out = load_case(case)
+    cfg = cfg_from(spec, conv_algo=algo)
+    net = DanNet(cfg).load_state_dict(w)
+    B, R, L = inp["reads"].shape
+    cpad = net.handle.query("cpad")
+    table = net.forward_u8(*input_tuple(inp), aux=True)                   # no tap: layer 1 by table
+    net.handle.set_tap(1)
+    net.forward_u8(*input_tuple(inp), aux=True)
+    tap1_table = net.handle.read_buffer("tap", B * R * L * cpad).reshape(B, R, L, cpad).copy()
+    net.handle.set_tap(0)
+    gemm = net.forward_u8(*input_tuple(inp), aux=True)                    # tap on the encoded input: layer 1 as a GEMM
+    enc = net.handle.read_buffer("tap", B * R * L * cpad).reshape(B, R, L, cpad).copy()
+    net.handle.set_tap(-1)
+    for k in ("vt_prob", "bp", "bin_logits", "vt_logits", "af", "cov", "vb", "vr"):
+        close(table[k], gemm[k].astype(np.float64), 1e-5, "%s:%s table vs gemm" % (case, k))
+    # conv1 + ReLU + BatchNorm in float64 from the exported encoded input (canonical 48-channel order -> the reference's order)
+    canon = list(range(40)) + ([40] if cfg.use_q else []) + ([41] if cfg.use_strand else []) + ([42, 43, 44] if cfg.use_mask else [])
+    x = torch.from_numpy(enc[..., canon].astype(np.float64)).permute(0, 3, 1, 2)            # (B, cin, R, L)
+    W = torch.from_numpy(w["conv1D_layers.0.weight"].astype(np.float64))
+    y = torch.nn.functional.conv2d(x, W, torch.from_numpy(w["conv1D_layers.0.bias"].astype(np.float64)), padding=(0, 1)).relu()
+    if cfg.use_bn:
+        g, b_ = w["bn1D_layers.0.weight"].astype(np.float64), w["bn1D_layers.0.bias"].astype(np.float64)
+        m, v = w["bn1D_layers.0.running_mean"].astype(np.float64), w["bn1D_layers.0.running_var"].astype(np.float64)
+        sc = g / np.sqrt(v + 1e-5)
+        y = y * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(b_ - m * sc).view(1, -1, 1, 1)
+    ref1 = y.permute(0, 2, 3, 1).numpy()                                                    # (B, R, L, cout)
+    close(tap1_table[..., :ref1.shape[-1]], ref1, 1e-5, case + ":conv1 by table vs float64")
+    assert np.all(tap1_table[..., ref1.shape[-1]:] == 0), "pad channels must stay zero"
+    net.close()
+
+
 def test_reference_call_signature_roundtrip():
     """DanNet.__call__ takes what trainer.py:569-572 passes: (B, L, R) int64 planes."""
     import torch
