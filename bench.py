@@ -544,7 +544,8 @@ def main():
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic, "traffic_stale": stale,
                          "frac_definition": "algorithmic direct-convolution FLOPs / kernel time / peak (the contract's definition; an "
-                                            "EFFECTIVE rate when the Winograd form runs); matrix-pipe utilisation = executed_frac",
+                                            "EFFECTIVE rate where the Winograd form runs and, fp32, layer 1 is summed from tables on the "
+                                            "vector ALUs); matrix-pipe utilisation = executed_frac (MFMA FLOPs actually issued)",
                          "conv_algo": "winograd_f23" if cfg.winograd_applies() else "direct",
                          "executed": round(executed, 3) if executed else None,
                          "executed_frac": round(executed / peak, 4) if executed else None,

@@ -121,6 +121,11 @@ class DanConfig:
             for l in range(2, self.layers + 1):
                 cin, cout, _ = self.layer_dims(l)
                 total -= cin * cout
+        if self.precision == PRECISION_F32:
+            # the fp32 path computes layer 1 from tables on the vector ALUs (csrc/dan_kernels.h L0_*): its 3 * cin * cout
+            # multiply-accumulates per position are algorithmic work but issue no MFMA
+            cin, cout, _ = self.layer_dims(1)
+            total -= 3 * cin * cout
         return total
 
     def input_bytes_per_site(self) -> int:
