@@ -140,6 +140,13 @@ void launch_highway_bias_grad(const float* dfeat, const float* feat, long long f
 void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, int feat_off, const float* h, long long h_layer,
                           float* partial, float* g_wc, long long wc_layer, float* g_bc, int n_sites, int R, int L, int H, int layers,
                           int layer_stride_b, hipStream_t s);
+// Layer 1's backward by bins (dan_train.hip): conv1's weight and bias gradients and the embedding gradient from ONE pass over
+// dz_1 = the transform (a1, a2, a_coef, a_mask) of WgradArgs -- no encode-form GEMM, no data-gradient launch, no embedding launches.
+// a: R, L, n_rows, a1, a2, a_coef, a_mask, the six token planes, emb, pe, partial (TRAIN_PARTIAL_WGS slices of 3 CPAD CPAD floats);
+// tot: L0B_FLOATS doubles (device scratch); w1: conv1's weights [n_out][n_in][3]; canon: reference channel -> canonical channel
+constexpr int L0_BINS_TOTALS = 208 * 128 + 2 * 3 * 10 * 128 + 3 * 5 * 128 + 32;
+void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
+                        float* g_b, float* g_emb, hipStream_t s);
 // embedding gradient with padding_idx 0 and scale_grad_by_freq (model.py:143-145) from dx0 rows [row][L][CPAD] (48 channels)
 void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
                            double* block_partial, float* g_emb, hipStream_t s);

@@ -2060,6 +2060,219 @@ void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Layer 1's backward by bins (round 5).  conv1's input column is a SUM of terms -- token embeddings + positional encoding, q, strand, three
+// mask flags (the encode above) -- so everything the step needs from dz_1 = d loss / d conv1 pre-activation is a handful of sums of dz_1:
+//     S[p][o]            = sum over rows of dz[row][p][o]                                        (-> bias gradient, positional term)
+//     BIN[kind][t][k][o] = sum over (row, p) with token_kind[row][p + t - 1] == k of dz[row][p][o]   (kind: read / reference token)
+//     GS[t][j][o]        = sum over (row, p) of dz[row][p][o] * scalar_j[row][p + t - 1]             (q, strand, refmatch, varmatch, lenmask)
+// from which  gW1[o][read emb e][t] = sum_k BIN[read][t][k][o] E[k][e] + sum_p S[p][o] pe[p + t - 1][e]  (ref emb: BIN[ref]),
+// gW1[o][scalar j][t] = GS[t][j][o],  gb1[o] = sum_p S[p][o],  and the embedding gradient (padding_idx 0, scale_grad_by_freq)
+// tot_read[k][e] = sum_{t,o} W1[o][e][t] BIN[read][t][k][o]  (what the conv's data gradient, summed per token, amounts to).
+// One pass over dz_1 (two tensors, 1.3 GB at 64 sites) replaces the K = 1.3 M weight-gradient GEMM in encode form, the 3-tap
+// data-gradient launch of layer 1 (whose only reader was the embedding gradient) and the embedding-gradient launches.
+// Deterministic: a workgroup walks its rows in order, a thread owns its accumulators, partials are added in workgroup order in double.
+// ------------------------------------------------------------------------------------------------
+constexpr int L0B_S = MPOS * CPAD;                               // floats of a workgroup's partial: S [MPOS][CPAD]
+constexpr int L0B_BIN = 2 * 3 * VOCAB * CPAD;                    //   BIN [kind 2][tap 3][token 10][CPAD]
+constexpr int L0B_GS = 3 * 5 * CPAD;                             //   GS [tap 3][scalar 5][CPAD]
+constexpr int L0B_CNT = 2 * 16;                                  //   token counts [kind 2][16]
+constexpr int L0B_FLOATS = L0B_S + L0B_BIN + L0B_GS + L0B_CNT;   // 36 256 <= 3 CPAD CPAD: the weight-gradient partial buffer holds them
+static_assert(L0B_FLOATS <= 3 * CPAD * CPAD, "layer-1 bins fit a slice of the weight-gradient partial buffer");
+static_assert(L0B_FLOATS == L0_BINS_TOTALS, "dan_train.h sizes the totals");
+// The binned sums ARE matrix products: BIN[kind][t] (and GS[t]) = A_kind x dz shifted by the tap, with A_kind [16][column] = ten one-hot
+// rows of the column's token (kind: read / reference) and, kind 0 only, the five scalar channels -- sixteen rows: one MFMA tile.  Products
+// with 0 / 1 are exact; a wave owns one 16-channel tile of all six (kind, tap) accumulators across the rows it walks.
+constexpr int L0B_DZ_S = CPAD + 4;                               // floats per dz row in LDS: 4 rows of a B fragment hit disjoint banks
+constexpr int L0B_A = 16;                                        // floats per column of A_kind
+
+__global__ __launch_bounds__(512) void l0_bins_kernel(WgradArgs a, int n_sites) {
+    extern __shared__ __attribute__((aligned(16))) float l0b_lds[];
+    float* const dz = l0b_lds + L0B_DZ_S;                        // [-1 .. L][L0B_DZ_S]: a zero row either side of the read
+    float* const amat = l0b_lds + (MPOS + 2) * L0B_DZ_S;         // [kind 2][MPOS][16]
+    const int tid = threadIdx.x, L = a.L, R = a.R, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c4 = tid & 31, pr = tid >> 5;
+    for (int i = tid; i < ((MPOS + 2) * L0B_DZ_S + 2 * MPOS * L0B_A) / 4; i += 512) ((v4f*)l0b_lds)[i] = splat(0.f);
+    constexpr int NS = (MPOS + 15) / 16;                         // 13 sweeps of 16 columns
+    v4f s_acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s_acc[k] = splat(0.f);
+    v4f acc[2][3];                                               // [kind][tap]: rows 4 (lane >> 4) + j of A x channel 16 wave + (lane & 15)
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[kd][t] = splat(0.f);
+    float cnt_read = 0.f, cnt_ref = 0.f;                         // (threads 0..9: occurrences of token tid)
+    const Coef3 ck = load_coef(a.a_coef, c4 * 4);
+    __syncthreads();
+    for (int row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
+        const int site = row / R;
+        // ---- stage dz of the row (the transform of the weight-gradient launches), add it to S; the row's A matrices
+        {
+            const v4f* s1 = (const v4f*)(a.a1 + (size_t)row * L * CPAD);
+            const v4f* s2 = (const v4f*)(a.a2 + (size_t)row * L * CPAD);
+            v4f r1[NS], r2[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int p = pr + 16 * k;
+                r1[k] = p < L ? s1[(size_t)p * (CPAD / 4) + c4] : splat(0.f);
+                r2[k] = p < L ? s2[(size_t)p * (CPAD / 4) + c4] : splat(0.f);
+            }
+            const size_t rbase = (size_t)row * L, sbase = (size_t)site * L;
+            int tok = 0, q = 0, st = 0, rf = 0, rm = 0, vm = 0;
+            if (tid < L) {
+                tok = a.reads[rbase + tid]; q = a.qual[rbase + tid]; st = a.strand[rbase + tid];
+                rf = a.ref[sbase + tid]; rm = a.ref_mask[sbase + tid]; vm = a.var_mask[sbase + tid];
+            }
+            const int agree_ref = __syncthreads_and((rm == 0) || (tok == rm));      // (also: the previous row's products are done with dz and A)
+            const int agree_var = __syncthreads_and((vm == 0) || (tok == vm));
+            if (tid < L) {
+                const int tk = min(tok, VOCAB - 1), rk = min(rf, VOCAB - 1);
+                float* a0 = amat + tid * L0B_A;
+                float* a1 = amat + (MPOS + tid) * L0B_A;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4f v0, v1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v0[j] = (4 * g + j == tk) ? 1.f : 0.f; v1[j] = (4 * g + j == rk) ? 1.f : 0.f; }
+                    if (g == 2) { v0[2] = (float)q * 0.01f; v0[3] = (float)st * 0.5f; }
+                    if (g == 3) { v0[0] = (rm != 0 && agree_ref) ? 1.f : 0.f; v0[1] = (vm != 0 && agree_var) ? 1.f : 0.f; v0[2] = (rm != 0) ? 1.f : 0.f; v0[3] = 0.f; }
+                    *(v4f*)(a0 + 4 * g) = v0; *(v4f*)(a1 + 4 * g) = v1;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int p = pr + 16 * k;
+                if (p < L) {
+                    const v4f v = apply_transform(r1[k], r2[k], ck, a.a_coef != nullptr, a.a_mask);
+                    *(v4f*)(dz + p * L0B_DZ_S + c4 * 4) = v;
+                    s_acc[k] += v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- acc[kind][t] += A_kind[.][column q] x dz[q - t + 1][.] over the columns, four per MFMA: A: row lane & 15, column 4 s + (lane >> 4)
+        {
+            const int m = lane & 15, kq = lane >> 4;
+            const float* pa0 = amat + kq * L0B_A + m;
+            const float* pa1 = pa0 + MPOS * L0B_A;
+            const float* pb = dz + (kq + 1) * L0B_DZ_S + 16 * wave + m;          // tap t reads row q - t + 1
+            const int n_steps = (L + 3) >> 2;
+#pragma unroll 4
+            for (int sI = 0; sI < n_steps; ++sI) {
+                const float a0 = pa0[sI * 4 * L0B_A], a1 = pa1[sI * 4 * L0B_A];
+                float bt[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bt[t] = pb[(sI * 4 - t) * L0B_DZ_S];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[0][t] = mfma16(a0, bt[t], acc[0][t]);
+                    acc[1][t] = mfma16(a1, bt[t], acc[1][t]);
+                }
+            }
+        }
+        if (tid < VOCAB) {
+            for (int p = 0; p < L; ++p) {
+                cnt_read += amat[p * L0B_A + tid];
+                if (row == site * R) cnt_ref += amat[(MPOS + p) * L0B_A + tid];              // the ref lookup: once per site
+            }
+        }
+    }
+    __syncthreads();
+    // ---- this workgroup's partial
+    float* out = a.partial + (size_t)blockIdx.x * (3 * CPAD * CPAD);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int p = pr + 16 * k;
+        if (p < MPOS) *(v4f*)(out + p * CPAD + c4 * 4) = s_acc[k];
+    }
+    {
+        const int n = lane & 15, g = lane >> 4, o = 16 * wave + n;
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;                     // row of A
+                    if (r < VOCAB) out[L0B_S + ((size_t)(kd * 3 + t) * VOCAB + r) * CPAD + o] = acc[kd][t][j];
+                    else if (kd == 0 && r < VOCAB + 5) out[L0B_S + L0B_BIN + ((size_t)t * 5 + (r - VOCAB)) * CPAD + o] = acc[kd][t][j];
+                }
+    }
+    if (tid < VOCAB) { out[L0B_S + L0B_BIN + L0B_GS + tid] = cnt_read; out[L0B_S + L0B_BIN + L0B_GS + 16 + tid] = cnt_ref; }
+    else if (tid < 16 || (tid >= 16 + VOCAB && tid < 32)) out[L0B_S + L0B_BIN + L0B_GS + tid] = 0.f;     // (the unused count slots)
+}
+
+// sums of the workgroups' partials in workgroup order (double)
+__global__ __launch_bounds__(256) void l0_bins_reduce_kernel(const float* __restrict__ partial, int wgs, double* __restrict__ tot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L0B_FLOATS) return;
+    tot[i] = ordered_sum<double>(wgs, [&](int w) { return (double)partial[(size_t)w * (3 * CPAD * CPAD) + i]; });
+}
+
+// gW1 (reference layout [cout][cin][3]), gb1, g_emb from the totals
+__global__ __launch_bounds__(256) void l0_grads_kernel(const double* __restrict__ tot, const float* __restrict__ emb, const float* __restrict__ pe,
+                                                       const float* __restrict__ w1, const int* __restrict__ canon, int L, int n_out, int n_in,
+                                                       float* __restrict__ g_w, float* __restrict__ g_b, float* __restrict__ g_emb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const double* S = tot;
+    const double* BIN = tot + L0B_S;
+    const double* GS = tot + L0B_S + L0B_BIN;
+    const double* CNT = tot + L0B_S + L0B_BIN + L0B_GS;
+    const int n_w = 3 * n_out * n_in;
+    if (idx < n_w) {
+        const int i = idx % n_in, o = (idx / n_in) % n_out, t = idx / (n_in * n_out);
+        const int c = canon[i];                                  // canonical channel of the reference's input channel i
+        double g = 0.0;
+        if (c < 2 * EMBED) {
+            const int kind = c / EMBED, e = c - kind * EMBED;
+            for (int k = 0; k < VOCAB; ++k) g += BIN[((size_t)(kind * 3 + t) * VOCAB + k) * CPAD + o] * (double)emb[k * EMBED + e];
+            for (int p = 0; p < L; ++p) {
+                const int pq = p + t - 1;
+                if (pq >= 0 && pq < L) g += S[(size_t)p * CPAD + o] * (double)pe[(size_t)pq * EMBED + e];
+            }
+        } else {
+            const int j = c - 2 * EMBED;
+            g = GS[((size_t)t * 5 + j) * CPAD + o];
+        }
+        g_w[((size_t)o * n_in + i) * 3 + t] = (float)g;
+    } else if (idx < n_w + n_out) {
+        const int o = idx - n_w;
+        double g = 0.0;
+        for (int p = 0; p < L; ++p) g += S[(size_t)p * CPAD + o];
+        g_b[o] = (float)g;
+    } else if (idx < n_w + n_out + VOCAB * EMBED) {
+        const int j = idx - n_w - n_out, k = j / EMBED, e = j % EMBED;
+        double g = 0.0;
+        if (k != 0) {                                            // padding_idx = base_enum['pad'] = 0
+            const double cr = CNT[k], cf = CNT[16 + k];
+            double tr = 0.0, tf = 0.0;
+            for (int t = 0; t < 3; ++t)
+                for (int o = 0; o < n_out; ++o) {
+                    tr += (double)w1[((size_t)o * n_in + e) * 3 + t] * BIN[((size_t)(0 * 3 + t) * VOCAB + k) * CPAD + o];
+                    tf += (double)w1[((size_t)o * n_in + EMBED + e) * 3 + t] * BIN[((size_t)(1 * 3 + t) * VOCAB + k) * CPAD + o];
+                }
+            if (cr > 0.0) g += tr / cr;
+            if (cf > 0.0) g += tf / cf;
+        }
+        g_emb[j] = (float)g;
+    }
+}
+
+int l0_bins_lds_bytes() { return ((MPOS + 2) * L0B_DZ_S + 2 * MPOS * L0B_A) * (int)sizeof(float); }
+
+void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
+                        float* g_b, float* g_emb, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)l0_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l0_bins_lds_bytes()); attr = true; }
+    const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
+    hipLaunchKernelGGL(l0_bins_kernel, dim3(wgs), dim3(512), l0_bins_lds_bytes(), s, a, n_sites);
+    hipLaunchKernelGGL(l0_bins_reduce_kernel, dim3((L0B_FLOATS + 255) / 256), dim3(256), 0, s, a.partial, wgs, tot);
+    const int total = 3 * n_out * n_in + n_out + VOCAB * EMBED;
+    hipLaunchKernelGGL(l0_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tot, a.emb, a.pe, w1, canon, a.L, n_out, n_in, g_w, g_b, g_emb);
+}
+
+// ------------------------------------------------------------------------------------------------
 // FC stack: tiled MFMA GEMM  C[m][n] = sum_k opA(m,k) opB(n,k) (+ bias[n], ReLU)
 // 128 x 128 x 32 tiles through LDS as in the inference fc_kernel; an operand that is K-slow in memory (X[k*ld + i]: the
 // transposed uses of the backward pass) is staged as [k][i] rows and its fragments are read with four ds_read_b32 (row

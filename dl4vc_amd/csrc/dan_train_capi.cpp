@@ -107,6 +107,7 @@ struct dan_trainer {
     float* d_split_ws = nullptr;                               // split-K partials of the forward FC GEMMs
     long long split_ws_floats = 0;
     double* d_emb_bp = nullptr;
+    double* d_l0tot = nullptr;                                  // layer 1's backward by bins: the totals (launch_l0_backward)
     int last_B = 0;
     // dan_train_backward_begin / _end: the step in flight and the event behind which the FC-side gradients are final
     bool pending = false;
@@ -413,7 +414,7 @@ int dan_train_finalize(dan_trainer_t* t) {
         (rc = talloc(t, &t->d_dn, rows * rowf, false)) || (rc = talloc(t, &t->d_dpool, (size_t)B * rowf, false))) return rc;
     if ((rc = talloc(t, &t->d_partial, (size_t)TRAIN_PARTIAL_WGS * 3 * CPAD * CPAD, false)) || (rc = talloc(t, &t->d_bias_partial, (size_t)2 * TRAIN_PARTIAL_WGS * CPAD, false)) ||
         (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD + 64 * HPAD, false)) ||
-        (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
+        (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_l0tot, (size_t)L0_BINS_TOTALS)) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
         (rc = talloc(t, &t->d_clip, 4))) return rc;
     if (H > 0) {
         t->split_hw_floats = (long long)8 * HPAD * L * HPAD;
@@ -764,6 +765,19 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             const int wgs = launch_train_wgrad(w, s);
             launch_wgrad_reduce(t->d_partial, t->d_bias_partial, wgs, 1, 2 * 16, CPAD, H, lp.cout, nullptr, gp(t, lp.bot_w), gp(t, lp.bot_b), s);
         }
+        if (l == 0) {
+            // layer 1: its weight and bias gradients AND the embedding gradient from one pass over dz_1 (dan_train.hip: layer 1's
+            // backward by bins) -- no encode-form GEMM, no data-gradient launch (its only reader was the embedding gradient)
+            WgradArgs w{};
+            w.R = R; w.L = L; w.n_rows = n_rows; w.a1 = dn; w.a_stride = CPAD; w.a2 = t->d_a[l]; w.a_coef = t->d_coef_b; w.a_mask = 1;
+            RowArgs e{};
+            fill_encode(e, t, B);
+            w.reads = e.reads; w.qual = e.qual; w.strand = e.strand; w.ref = e.ref; w.ref_mask = e.ref_mask; w.var_mask = e.var_mask;
+            w.emb = e.emb; w.pe = e.pe; w.partial = t->d_partial;
+            launch_l0_backward(w, B, t->d_l0tot, pp(t, lp.conv_w), t->d_canon, lp.cout, lp.cin, gp(t, lp.conv_w), gp(t, lp.conv_b), gp(t, t->p_emb), s);
+            cur ^= 1;
+            continue;
+        }
         {   // conv weight gradient: dz_l = (A dn + B a_l + C) * (a_l > 0);  gW[o][c][t] = sum_p dz[p][o] u_l[p + (t-1) d][c]
             WgradArgs w{};
             w.R = R; w.L = L; w.n_rows = n_rows; w.a1 = dn; w.a_stride = CPAD; w.a2 = t->d_a[l]; w.a_coef = t->d_coef_b; w.a_mask = 1;
@@ -806,11 +820,6 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
         }
         if (l > 0 && pool_after(c, l)) launch_read_mean(t->d_du, t->d_dpool, B, R, L, nullptr, s);     // u_l = x_{l-1} + mean_r x_{l-1}
         cur ^= 1;
-    }
-    {
-        RowArgs e{};
-        fill_encode(e, t, B);
-        launch_embedding_grad(t->d_du, e.reads, e.ref, B, R, L, t->d_emb_partial, t->d_emb_bp, gp(t, t->p_emb), s);
     }
     HIPT(t, hipGetLastError());
     t->pending = true;
