@@ -147,6 +147,11 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
 constexpr int L0_BINS_TOTALS = 208 * 128 + 2 * 3 * 10 * 128 + 3 * 5 * 128 + 32;
 void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
                         float* g_b, float* g_emb, hipStream_t s);
+// Layer 1's forward by table (the inference walk of dan_kernels.h L0_*, tables rebuilt from the step's weights): tab = l0_tab_floats(L)
+// floats; inv: canonical channel -> reference channel or -1.  The forward writes a_1 = relu(conv1 + bias) [row][L][CPAD] and, if stats,
+// one entry of BatchNorm sums per row; returns the number of entries.
+void launch_l0_train_tables(const float* w1, const int* inv, const float* emb, const float* pe, int L, int n_out, int n_in, float* tab, hipStream_t s);
+int launch_l0_train_forward(const RowArgs& enc, const float* tab, const float* bias, int n_rows, float* a_out, float* stats, hipStream_t s);
 // embedding gradient with padding_idx 0 and scale_grad_by_freq (model.py:143-145) from dx0 rows [row][L][CPAD] (48 channels)
 void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
                            double* block_partial, float* g_emb, hipStream_t s);

@@ -2158,7 +2158,6 @@ __global__ __launch_bounds__(512) void l0_bins_kernel(WgradArgs a, int n_sites) 
             const float* pa1 = pa0 + MPOS * L0B_A;
             const float* pb = dz + (kq + 1) * L0B_DZ_S + 16 * wave + m;          // tap t reads row q - t + 1
             const int n_steps = (L + 3) >> 2;
-#pragma unroll 4
             for (int sI = 0; sI < n_steps; ++sI) {
                 const float a0 = pa0[sI * 4 * L0B_A], a1 = pa1[sI * 4 * L0B_A];
                 float bt[3];
@@ -2270,6 +2269,124 @@ void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const floa
     hipLaunchKernelGGL(l0_bins_reduce_kernel, dim3((L0B_FLOATS + 255) / 256), dim3(256), 0, s, a.partial, wgs, tot);
     const int total = 3 * n_out * n_in + n_out + VOCAB * EMBED;
     hipLaunchKernelGGL(l0_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tot, a.emb, a.pe, w1, canon, a.L, n_out, n_in, g_w, g_b, g_emb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer 1's forward by table (the inference path's walk, dan_kernels.h L0_*): the weights change every step, so the tables -- token pairs,
+// positional term in three variants, scalar-channel rows -- are rebuilt from the current conv1 weights and embeddings by one small launch
+// per step; the walk writes a_1 = relu(conv1 + bias) and the row's BatchNorm sums.  Replaces the encode-form 3-tap row launch of layer 1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l0_train_tables_kernel(const float* __restrict__ w1, const int* __restrict__ inv, const float* __restrict__ emb,
+                                                              const float* __restrict__ pe, int L, int n_out, int n_in, float* __restrict__ tab) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    auto W = [&](int o, int c, int t) -> double { return (o < n_out && inv[c] >= 0) ? (double)w1[((size_t)o * n_in + inv[c]) * 3 + t] : 0.0; };
+    const int n_tj = 3 * L0_NTJ * CPAD, n_sc = 5 * 3 * CPAD, n_pe = 3 * L * CPAD;
+    if (idx < n_tj) {
+        const int o = idx % CPAD, ent = (idx / CPAD) % L0_NTJ, t = idx / (CPAD * L0_NTJ);
+        double v = 0.0;
+        if (ent < 100) {
+            const int ta = ent / 10, tb = ent % 10;
+            for (int e = 0; e < EMBED; ++e) v += W(o, e, t) * (double)emb[ta * EMBED + e] + W(o, EMBED + e, t) * (double)emb[tb * EMBED + e];
+        }
+        tab[L0_TJ_OFF + idx] = (float)v;
+    } else if (idx < n_tj + n_sc) {
+        const int j = idx - n_tj, o = j % CPAD, kt = j / CPAD, k = kt / 3, t = kt % 3;
+        tab[L0_WSC_OFF + j] = (float)W(o, 2 * EMBED + k, t);
+    } else if (idx < n_tj + n_sc + n_pe) {
+        const int j = idx - n_tj - n_sc, o = j % CPAD, p = (j / CPAD) % L, var = j / (CPAD * L);
+        double v = 0.0;
+        for (int t = 0; t < 3; ++t) {
+            const int pq = p + t - 1;
+            if (pq < 0 || pq >= L || (t == 0 && var == 1) || (t == 2 && var == 2)) continue;
+            for (int e = 0; e < EMBED; ++e) v += (W(o, e, t) + W(o, EMBED + e, t)) * (double)pe[(size_t)pq * EMBED + e];
+        }
+        tab[L0_PE_OFF + j] = (float)v;
+    }
+}
+
+__global__ __launch_bounds__(512) void l0_train_forward_kernel(EncodeSrc e, const float* __restrict__ tab, const float* __restrict__ bias_p, int R, int L,
+                                                               float* __restrict__ a_out, float* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float tokf[(MPOS + 2) * L0_TOK];
+    __shared__ __attribute__((aligned(16))) float red[16][2][CPAD];
+    const int row = blockIdx.x, site = row / R, tid = threadIdx.x;
+    const size_t rbase = (size_t)row * L, sbase = (size_t)site * L;
+    int tok = 0, rm = 0, vm = 0;
+    if (tid < L) { tok = e.reads[rbase + tid]; rm = e.ref_mask[sbase + tid]; vm = e.var_mask[sbase + tid]; }
+    const int agree_ref = __syncthreads_and((rm == 0) || (tok == rm));      // model.py:592-593
+    const int agree_var = __syncthreads_and((vm == 0) || (tok == vm));
+    if (tid <= L + 1) {                                          // thread j stages column j - 1; the columns either side of the read: the zero entry
+        const int pc = tid - 1;
+        const bool inside = pc >= 0 && pc < L;
+        int tk = 0, qq = 0, ss = 0, rr = 0, mm = 0, vv = 0;
+        if (inside) {
+            tk = e.reads[rbase + pc]; qq = e.qual[rbase + pc]; ss = e.strand[rbase + pc];
+            rr = e.ref[sbase + pc]; mm = e.ref_mask[sbase + pc]; vv = e.var_mask[sbase + pc];
+        }
+        const v4f t0 = {__builtin_bit_cast(float, inside ? min(tk, VOCAB - 1) * 10 + min(rr, VOCAB - 1) : 100), (float)qq * 0.01f, (float)ss * 0.5f,
+                        (inside && mm != 0) ? 1.f : 0.f};
+        const v4f t1 = {(inside && vv != 0 && agree_var) ? 1.f : 0.f, (tid == 0 && agree_ref) ? 1.f : 0.f, 0.f, 0.f};
+        *(v4f*)(tokf + tid * L0_TOK) = t0; *(v4f*)(tokf + tid * L0_TOK + 4) = t1;
+    }
+    __syncthreads();
+    const int c4 = tid & 31, pr = tid >> 5;
+    const v4f bias = *(const v4f*)(bias_p + c4 * 4);
+    v4f wq[3], wst[3], wlen[3], wvar[3];
+    {
+        const float agree = tokf[5];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            auto wv = [&](int k) { return *(const v4f*)(tab + L0_WSC_OFF + (k * 3 + t) * CPAD + c4 * 4); };
+            wq[t] = wv(0); wst[t] = wv(1); wvar[t] = wv(3);
+            wlen[t] = wv(4) + agree * wv(2);
+        }
+    }
+    const v4f* tj = (const v4f*)(tab + L0_TJ_OFF) + c4;
+    const v4f* pev = (const v4f*)(tab + L0_PE_OFF) + c4;
+    v4f s0 = splat(0.f), s1 = splat(0.f);
+    v4f* out = (v4f*)(a_out + (size_t)row * L * CPAD) + c4;
+    constexpr int NS = (MPOS + 15) / 16;
+#pragma unroll 4
+    for (int k = 0; k < NS; ++k) {
+        const int p = pr + 16 * k;
+        if (p < L) {
+            const int var = (p == 0) ? 1 : (p == L - 1) ? 2 : 0;
+            v4f acc = bias + pev[((size_t)var * L + p) * (CPAD / 4)];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const v4f sa = *(const v4f*)(tokf + (p + t) * L0_TOK);
+                const float sv = tokf[(p + t) * L0_TOK + 4];
+                acc += tj[(size_t)(t * L0_NTJ + __builtin_bit_cast(int, sa[0])) * (CPAD / 4)];
+                acc += sa[1] * wq[t] + sa[2] * wst[t] + sa[3] * wlen[t] + sv * wvar[t];
+            }
+            v4f v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[j], 0.f);
+            out[(size_t)p * (CPAD / 4)] = v;
+            s0 += v; s1 += v * v;
+        }
+    }
+    if (stats) {                                                 // the row's sums, the sixteen position classes added in order
+        *(v4f*)(&red[pr][0][c4 * 4]) = s0; *(v4f*)(&red[pr][1][c4 * 4]) = s1;
+        __syncthreads();
+        if (tid < 2 * CPAD) {
+            const int st = tid / CPAD, ch = tid % CPAD;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += red[i][st][ch];
+            stats[((size_t)row * 2 + st) * CPAD + ch] = sum;
+        }
+    }
+}
+
+void launch_l0_train_tables(const float* w1, const int* inv, const float* emb, const float* pe, int L, int n_out, int n_in, float* tab, hipStream_t s) {
+    const int total = 3 * L0_NTJ * CPAD + 5 * 3 * CPAD + 3 * L * CPAD;
+    hipLaunchKernelGGL(l0_train_tables_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w1, inv, emb, pe, L, n_out, n_in, tab);
+}
+
+int launch_l0_train_forward(const RowArgs& enc, const float* tab, const float* bias, int n_rows, float* a_out, float* stats, hipStream_t s) {
+    EncodeSrc e{enc.reads, enc.qual, enc.strand, enc.ref, enc.ref_mask, enc.var_mask, enc.emb, enc.pe};
+    hipLaunchKernelGGL(l0_train_forward_kernel, dim3(n_rows), dim3(512), 0, s, e, tab, bias, enc.R, enc.L, a_out, stats);
+    return n_rows;                                               // entries of stats written
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -108,6 +108,7 @@ struct dan_trainer {
     long long split_ws_floats = 0;
     double* d_emb_bp = nullptr;
     double* d_l0tot = nullptr;                                  // layer 1's backward by bins: the totals (launch_l0_backward)
+    float* d_l0tab = nullptr;                                   // layer 1's forward by table: rebuilt every step (launch_l0_train_tables)
     int last_B = 0;
     // dan_train_backward_begin / _end: the step in flight and the event behind which the FC-side gradients are final
     bool pending = false;
@@ -414,7 +415,7 @@ int dan_train_finalize(dan_trainer_t* t) {
         (rc = talloc(t, &t->d_dn, rows * rowf, false)) || (rc = talloc(t, &t->d_dpool, (size_t)B * rowf, false))) return rc;
     if ((rc = talloc(t, &t->d_partial, (size_t)TRAIN_PARTIAL_WGS * 3 * CPAD * CPAD, false)) || (rc = talloc(t, &t->d_bias_partial, (size_t)2 * TRAIN_PARTIAL_WGS * CPAD, false)) ||
         (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD + 64 * HPAD, false)) ||
-        (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_l0tot, (size_t)L0_BINS_TOTALS)) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
+        (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_l0tot, (size_t)L0_BINS_TOTALS)) || (rc = talloc(t, &t->d_l0tab, l0_tab_floats(L))) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
         (rc = talloc(t, &t->d_clip, 4))) return rc;
     if (H > 0) {
         t->split_hw_floats = (long long)8 * HPAD * L * HPAD;
@@ -627,8 +628,14 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
         {   // a_l = relu(conv(u_l) + b), u_l = x_{l-1} (+ read-mean of x_{l-1} when layer l-1 pools; model.py:742,749)
             RowArgs a{};
             a.R = R; a.L = L;
-            if (l == 0) { a.mode = 0; fill_encode(a, t, B); }
-            else if (t->lazy_x[l - 1]) { a.mode = 1; a.src1 = t->d_a[l - 1]; a.s1_stride = CPAD; a.coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
+            if (l == 0) {
+                // layer 1 by table: the tables from this step's weights, then the walk (dan_train.hip)
+                fill_encode(a, t, B);
+                launch_l0_train_tables(pp(t, lp.conv_w), t->d_inv, a.emb, a.pe, L, lp.cout, lp.cin, t->d_l0tab, s);
+                stat_entries = launch_l0_train_forward(a, t->d_l0tab, bias, n_rows, t->d_a[l], c.use_bn ? t->d_stats : nullptr, s);
+                if (stat_entries > stat_cap) return failt(t, DAN_ERR_STATE, "layer 1's forward writes %d statistics entries, the buffer holds %d", stat_entries, stat_cap);
+            } else {
+            if (t->lazy_x[l - 1]) { a.mode = 1; a.src1 = t->d_a[l - 1]; a.s1_stride = CPAD; a.coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
             else { a.mode = 1; a.src1 = t->d_x[l - 1]; a.s1_stride = CPAD; a.pool_in = t->d_pool[l]; }
             a.w1 = t->pk_conv_f[l]; a.taps = 3; a.kg = lp.kg; a.dil = lp.dil;
             if (t->wino_layer[l]) { a.w1 = t->pk_wino_f[l]; a.wino = 1; }
@@ -636,6 +643,7 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             a.stats = c.use_bn ? t->d_stats : nullptr;
             stat_entries = launch_train_row(a, n_rows, s, stat_cap);
             if ((rc = check_row_launch(t, stat_entries, "conv forward", l))) return rc;
+            }
         }
         if (c.use_bn) {                                      // batch statistics over (B, R, L) per channel (model.py:750-751, train mode)
             int nb = 0;
