@@ -69,7 +69,7 @@ struct WgradArgs {
     const float* a2;                        // optional second tensor for the affine / mask (same stride)
     const float* a_coef;                    // [3][CPAD] as RowArgs::coef, or nullptr
     int a_mask;                             // A = (a2 > 0) ? A : 0
-    int b_mode;                             // 0 = encode, 1 = rows
+    int b_mode;                             // (1 = rows; the encode form is gone: layer 1 goes through launch_l0_backward)
     const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
     const float *emb, *pe;
     const float* b1;                        // B rows, CPAD stride
@@ -152,10 +152,6 @@ void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const floa
 // one entry of BatchNorm sums per row; returns the number of entries.
 void launch_l0_train_tables(const float* w1, const int* inv, const float* emb, const float* pe, int L, int n_out, int n_in, float* tab, hipStream_t s);
 int launch_l0_train_forward(const RowArgs& enc, const float* tab, const float* bias, int n_rows, float* a_out, float* stats, hipStream_t s);
-// embedding gradient with padding_idx 0 and scale_grad_by_freq (model.py:143-145) from dx0 rows [row][L][CPAD] (48 channels)
-void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
-                           double* block_partial, float* g_emb, hipStream_t s);
-
 // ---- FC stack ------------------------------------------------------------------------------------------------------------------------
 // C[m][n] (+)= sum_k opA(m,k) * opB(n,k);  an operand is K-contiguous (X[i*ld + k]) or K-slow (X[k*ld + i])
 // split_ws: workspace for split-K partials (used when the tile grid cannot fill the chip and K is long), or nullptr

@@ -19,45 +19,14 @@
 namespace dan {
 
 // ------------------------------------------------------------------------------------------------
-// encode one read into an LDS image (dl4vc/model.py:450-627): canonical 48-channel order
+// The token planes of a batch (dl4vc/model.py:450-627).  Nothing in the training step builds the encoded 48-channel input any more:
+// layer 1 runs forward from tables and backward as binned sums (the end of this file); canonical channel order of its weights
 //   [read emb+pe (20) | ref emb+pe (20) | q*0.01 | strand*0.5 | refmatch | varmatch | lenmask | 0 0 0]
-// Every thread of the workgroup must call (barrier inside).  Rows [row_lo, row_hi) of the read are written to
-// img + (p - row_lo + row_off) * stride; the agree predicates are over the whole read.
 // ------------------------------------------------------------------------------------------------
 struct EncodeSrc {
     const uint8_t *reads, *qual, *strand, *ref, *ref_mask, *var_mask;
     const float *emb, *pe;
 };
-__device__ __forceinline__ void encode_rows(float* img, int stride, int row_off, int row_lo, int row_hi, const EncodeSrc& e,
-                                            size_t read_idx, int site, int L, int tid) {
-    const size_t rbase = read_idx * (size_t)L, sbase = (size_t)site * L;
-    const int p = tid;
-    const bool in = p < L;
-    int tok = 0, q = 0, st = 0, rf = 0, rm = 0, vm = 0;
-    if (in) {
-        tok = e.reads[rbase + p]; q = e.qual[rbase + p]; st = e.strand[rbase + p];
-        rf = e.ref[sbase + p]; rm = e.ref_mask[sbase + p]; vm = e.var_mask[sbase + p];
-    }
-    const int agree_ref = __syncthreads_and((rm == 0) || (tok == rm));      // model.py:592-593
-    const int agree_var = __syncthreads_and((vm == 0) || (tok == vm));
-    if (in && p >= row_lo && p < row_hi) {
-        float* row = img + (size_t)(p - row_lo + row_off) * stride;
-        const float* er = e.emb + min(tok, VOCAB - 1) * EMBED;
-        const float* ef = e.emb + min(rf, VOCAB - 1) * EMBED;
-        const float* pp = e.pe + p * EMBED;
-#pragma unroll
-        for (int k = 0; k < EMBED; ++k) {
-            const float pv = pp[k];
-            row[k] = er[k] + pv;
-            row[EMBED + k] = ef[k] + pv;
-        }
-        row[40] = (float)q * 0.01f;
-        row[41] = (float)st * 0.5f;
-        row[42] = (rm != 0 && agree_ref) ? 1.f : 0.f;
-        row[43] = (vm != 0 && agree_var) ? 1.f : 0.f;
-        row[44] = (rm != 0) ? 1.f : 0.f;
-    }
-}
 
 // The same with the three constants of the thread's channels already in registers.  Every staging loop below walks positions
 // with a stride that is a multiple of the row's vector count, so a thread meets the SAME four channels in every iteration:
@@ -126,7 +95,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
             r2[k] = (ok && s2) ? s2[i] : splat(0.f);
         }
     };
-    if (a.mode != 0 && (int)blockIdx.x < n_rows) request(blockIdx.x, tid0);
+    if ((int)blockIdx.x < n_rows) request(blockIdx.x, tid0);
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
     // (an opaque copy of the thread index per read: hipcc otherwise forms every per-lane address of the body ahead of the loop
     // and keeps them -- spilled -- through the GEMMs)
@@ -135,10 +104,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
     const int lane = tid & 63;
     const int site = row / a.R;
     const int next = row + (int)gridDim.x;
-    if (a.mode == 0) {
-        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
-        encode_rows(xs, LDS_S, HALO, 0, L, e, (size_t)row, site, L, tid);
-    } else {
+    {
         const v4f* pl = a.pool_in ? (const v4f*)(a.pool_in + (size_t)site * L * CPAD) : nullptr;
         if (vpr < CPAD / 4) {                                    // (a narrower tensor: the columns it does not cover must read zero)
             for (int i = tid; i < TR_LDS_ROWS * LDS_S / 4; i += SEG_THREADS) ((v4f*)xs)[i] = splat(0.f);
@@ -236,22 +202,14 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_row_kernel(RowAr
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = splat(0.f);
         conv_gemm(acc, xs, w, first, a.kg, a.taps, a.dil, lane, m_base, cnt);
-        if (a.mode != 0) request(min(next, n_rows - 1), tid);
-        else {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { r1[k] = splat(0.f); r2[k] = splat(0.f); }
-        }
+        request(min(next, n_rows - 1), tid);
     } else {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 acc[m][n] = (m < cnt) ? *(const v4f*)(xs + (HALO + (m_base + m) * 16 + pos) * LDS_S + chb[n]) : splat(0.f);
-        if (a.mode != 0) request(min(next, n_rows - 1), tid);
-        else {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { r1[k] = splat(0.f); r2[k] = splat(0.f); }
-        }
+        request(min(next, n_rows - 1), tid);
     }
     // ---- epilogue
     v4f s0[NT], s1v[NT], bias[NT];
@@ -361,12 +319,7 @@ __global__ __launch_bounds__(RH_THREADS, 2) void train_rowh_kernel(RowArgs a, in
         const int site = row / a.R;
         const int p0 = half * (MTW * 16), cnt = half ? MT - MTW : MTW;
         // ---- the image: rows [p0 - HALO, p0 + 112 + HALO) of the read, zero outside the window
-        if (a.mode == 0) {
-            for (int i = tid; i < RH_ROWS * LDS_S / 4; i += RH_THREADS) ((v4f*)xs)[i] = splat(0.f);
-            __syncthreads();
-            EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
-            encode_rows(xs, LDS_S, 0, p0 - HALO, p0 - HALO + RH_ROWS, e, (size_t)row, site, L, tid);
-        } else {
+        {
             constexpr int NP = RH_ROWS * (CPAD / 4) / RH_THREADS;                   // 15
             static_assert(NP * RH_THREADS == RH_ROWS * (CPAD / 4), "the staging covers the image exactly");
             const v4f* s1 = (const v4f*)(a.src1 + (size_t)row * L * CPAD);
@@ -723,18 +676,19 @@ __global__ __launch_bounds__(TP_THREADS, 4) void train_point_kernel(RowArgs a, l
 static bool row_half_units(const RowArgs& a, bool f2) {
     const bool src2 = a.src2 != nullptr, pool = a.pool_in != nullptr;
     return !a.wino && a.w1 && a.taps == 3 && a.out1 && !a.w2 && !a.add1 && !a.addb && (f2 || (!a.add2 && !a.stat_aux)) &&
-           (a.mode == 0 || a.s1_stride == CPAD) && a.L <= RH_THREADS && !(pool && (src2 || f2)) && !(f2 && !src2) &&
+           a.s1_stride == CPAD && a.L <= RH_THREADS && !(pool && (src2 || f2)) && !(f2 && !src2) &&
            !(a.mask_src2 && !src2);
 }
 bool train_row_fuses_second_product(const RowArgs& a) {
-    const bool pointwise = a.mode == 1 && !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
+    const bool pointwise = !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
     return !pointwise && row_half_units(a, true);
 }
 
 // Returns the number of `stats` entries the launch writes (reads for the whole-read form, half-read units for the half-read form,
 // 64-position tiles for the pointwise one), or TRAIN_ROW_ERR_* without launching.
 int launch_train_row(const RowArgs& a, int n_rows, hipStream_t s, int stat_cap) {
-    const bool pointwise = a.mode == 1 && !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
+    if (a.mode == 0) return TRAIN_ROW_ERR_FORM;                  // (the encode form is gone: layer 1 runs from tables, launch_l0_train_forward)
+    const bool pointwise = !a.pool_in && !a.wino && (a.w1 == nullptr || a.taps == 1);
     static const int n_cus_h = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
@@ -835,13 +789,11 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                         r1[k] = ok ? s1[g] : splat(0.f);
                         r2[k] = (ok && s2) ? s2[g] : splat(0.f);
                     }
-                    if (a.b_mode != 0) {
 #pragma unroll
-                        for (int k = 0; k < NITB; ++k) {
-                            const int i = tid + k * SEG_THREADS;
-                            const int p = p0 - HALO + (i >> 5);
-                            rb[k] = (p >= 0 && p < L) ? b1[(size_t)p * (CPAD / 4) + (i & 31)] : splat(0.f);
-                        }
+                    for (int k = 0; k < NITB; ++k) {
+                        const int i = tid + k * SEG_THREADS;
+                        const int p = p0 - HALO + (i >> 5);
+                        rb[k] = (p >= 0 && p < L) ? b1[(size_t)p * (CPAD / 4) + (i & 31)] : splat(0.f);
                     }
 #pragma unroll
                     for (int k = 0; k < NIT; ++k) {
@@ -853,12 +805,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                             bsum += v;
                         }
                     }
-                    if (a.b_mode == 0) {
-                        for (int i = tid; i < BROWS * WG_S / 4; i += SEG_THREADS) ((v4f*)sb)[i] = splat(0.f);
-                        __syncthreads();
-                        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
-                        encode_rows(sb, WG_S, 0, p0 - HALO, p0 + WG_CH + HALO, e, (size_t)row, site, L, tid);
-                    } else {
+                    {
                         const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
                         const Coef3 cb = load_coef(a.b_coef, (tid & 31) * 4);
 #pragma unroll
@@ -897,12 +844,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void train_wgrad_kernel(Wgr
                             }
                         }
                     }
-                    if (a.b_mode == 0) {
-                        for (int i = tid; i < BROWS * WG_S / 4; i += SEG_THREADS) ((v4f*)sb)[i] = splat(0.f);
-                        __syncthreads();
-                        EncodeSrc e{a.reads, a.qual, a.strand, a.ref, a.ref_mask, a.var_mask, a.emb, a.pe};
-                        encode_rows(sb, WG_S, 0, p0 - HALO, p0 + WG_CH + HALO, e, (size_t)row, site, L, tid);
-                    } else {
+                    {
                         const v4f* pl4 = a.b_pool ? (const v4f*)(a.b_pool + (size_t)site * L * CPAD) : nullptr;
                         const Coef3 cb = load_coef(a.b_coef, (tid & 31) * 4);
                         v4f rb[NITB], rp[NITB];
@@ -1306,13 +1248,13 @@ int launch_train_wgrad(const WgradArgs& a, hipStream_t s) {
     auto balanced = [](int n, int cap) { const int rounds = (n + cap - 1) / cap; return (n + rounds - 1) / rounds; };
     const int wgs = balanced(a.n_rows, TRAIN_PARTIAL_WGS);
     const dim3 grid((unsigned)wgs), blk(SEG_THREADS);
-    if (a.taps == 1 && a.b_mode != 0 && !a.b_pool && !a.a_coef) {   // 1x1 forms: two workgroups per CU (train_wgrad1_kernel)
+    if (a.taps == 1 && !a.b_pool && !a.a_coef) {   // 1x1 forms: two workgroups per CU (train_wgrad1_kernel)
         const int wgs2 = balanced(a.n_rows, 2 * TRAIN_PARTIAL_WGS);
         if (a.o_tiles <= 2) hipLaunchKernelGGL((train_wgrad1_kernel<false, 1>), dim3((unsigned)wgs2), blk, 0, s, a);
         else hipLaunchKernelGGL((train_wgrad1_kernel<true, KGC>), dim3((unsigned)wgs2), blk, 0, s, a);
         return wgs2;
     }
-    if (a.taps == 3 && a.b_mode != 0 && !a.b_pool && a.a2 && a.a_stride == CPAD && a.c_tiles == KGC && a.o_tiles == KGC) {
+    if (a.taps == 3 && !a.b_pool && a.a2 && a.a_stride == CPAD && a.c_tiles == KGC && a.o_tiles == KGC) {
         hipLaunchKernelGGL((train_wgrad3_kernel<KGC>), grid, blk, 0, s, a);                    // the next chunk in flight under the MFMAs
         return wgs;
     }
@@ -1987,81 +1929,8 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// embedding gradient (dl4vc/model.py:143-145,450-451): two lookups (reads: B*L*R indices, ref: B*L indices), each with
-// padding_idx 0 and scale_grad_by_freq -- a row's gradient is the MEAN over its occurrences in that lookup
-// ------------------------------------------------------------------------------------------------
-constexpr int EMB_W = 2 * EMBED + 2;                            // per token: 20 read-lookup sums, 20 ref-lookup sums, 2 counts
-__global__ __launch_bounds__(512) void embedding_partial_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ reads,
-                                                                const uint8_t* __restrict__ ref, int R, int L, float* __restrict__ partial) {
-    // the row's 40 embedding channels go through LDS first (coalesced 16-byte loads, all in flight at once): the per-(token,
-    // channel) sums below then walk LDS in position order -- the same sums in the same order as a walk over global memory,
-    // which was 201 dependent 4-byte loads per thread (0.40 ms per step at 64 sites; 0.1 ms now)
-    __shared__ uint8_t tok[256], rtk[256];
-    __shared__ __attribute__((aligned(16))) float xe[MPOS * 2 * EMBED];
-    const int row = blockIdx.x, site = row / R, tid = threadIdx.x;
-    if (tid < L) { tok[tid] = min((int)reads[(size_t)row * L + tid], VOCAB - 1); rtk[tid] = min((int)ref[(size_t)site * L + tid], VOCAB - 1); }
-    {
-        constexpr int V = 2 * EMBED / 4;                         // 10 vectors of a position
-        const v4f* xg = (const v4f*)(dx0 + (size_t)row * L * CPAD);
-        for (int i = tid; i < L * V; i += 512) {
-            const int p = i / V, c = i - p * V;
-            ((v4f*)xe)[i] = xg[(size_t)p * (CPAD / 4) + c];
-        }
-    }
-    __syncthreads();
-    if (tid < VOCAB * EMB_W) {
-        const int k = tid / EMB_W, e = tid % EMB_W;
-        const float* x = xe;
-        constexpr int XS = 2 * EMBED;
-        float sum = 0.f;
-        if (e < EMBED) { for (int p = 0; p < L; ++p) if (tok[p] == k) sum += x[p * XS + e]; }
-        else if (e < 2 * EMBED) { for (int p = 0; p < L; ++p) if (rtk[p] == k) sum += x[p * XS + e]; }
-        else if (e == 2 * EMBED) { for (int p = 0; p < L; ++p) sum += (tok[p] == k); }
-        else { if (row == site * R) for (int p = 0; p < L; ++p) sum += (rtk[p] == k); }       // the ref lookup: once per site
-        partial[(size_t)row * VOCAB * EMB_W + tid] = sum;
-    }
-}
-
-constexpr int EMB_ROWS_PER_BLOCK = 64;
-__global__ __launch_bounds__(512) void embedding_block_kernel(const float* __restrict__ partial, int n_rows, double* __restrict__ bp) {
-    const int tid = threadIdx.x;
-    if (tid >= VOCAB * EMB_W) return;
-    const int lo = blockIdx.x * EMB_ROWS_PER_BLOCK, hi = min(n_rows, lo + EMB_ROWS_PER_BLOCK);
-    double sum = 0.0;
-    for (int r = lo; r < hi; ++r) sum += (double)partial[(size_t)r * VOCAB * EMB_W + tid];
-    bp[(size_t)blockIdx.x * VOCAB * EMB_W + tid] = sum;
-}
-
-__global__ __launch_bounds__(512) void embedding_reduce_kernel(const double* __restrict__ bp, int n_blocks, float* __restrict__ g_emb) {
-    __shared__ double tot[VOCAB * EMB_W];
-    const int tid = threadIdx.x;
-    if (tid < VOCAB * EMB_W) {
-        tot[tid] = ordered_sum<double>(n_blocks, [&](int b) { return bp[(size_t)b * VOCAB * EMB_W + tid]; });
-    }
-    __syncthreads();
-    if (tid < VOCAB * EMBED) {
-        const int k = tid / EMBED, e = tid % EMBED;
-        double g = 0.0;
-        if (k != 0) {                                            // padding_idx = base_enum['pad'] = 0
-            const double cr = tot[k * EMB_W + 2 * EMBED], cf = tot[k * EMB_W + 2 * EMBED + 1];
-            if (cr > 0.0) g += tot[k * EMB_W + e] / cr;
-            if (cf > 0.0) g += tot[k * EMB_W + EMBED + e] / cf;
-        }
-        g_emb[tid] = (float)g;
-    }
-}
-
-void launch_embedding_grad(const float* dx0, const uint8_t* reads, const uint8_t* ref, int n_sites, int R, int L, float* partial,
-                           double* block_partial, float* g_emb, hipStream_t s) {
-    const int n_rows = n_sites * R, nb = (n_rows + EMB_ROWS_PER_BLOCK - 1) / EMB_ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(embedding_partial_kernel, dim3(n_rows), dim3(512), 0, s, dx0, reads, ref, R, L, partial);
-    hipLaunchKernelGGL(embedding_block_kernel, dim3(nb), dim3(512), 0, s, partial, n_rows, block_partial);
-    hipLaunchKernelGGL(embedding_reduce_kernel, dim3(1), dim3(512), 0, s, block_partial, nb, g_emb);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Layer 1's backward by bins (round 5).  conv1's input column is a SUM of terms -- token embeddings + positional encoding, q, strand, three
-// mask flags (the encode above) -- so everything the step needs from dz_1 = d loss / d conv1 pre-activation is a handful of sums of dz_1:
+// mask flags -- so everything the step needs from dz_1 = d loss / d conv1 pre-activation is a handful of sums of dz_1:
 //     S[p][o]            = sum over rows of dz[row][p][o]                                        (-> bias gradient, positional term)
 //     BIN[kind][t][k][o] = sum over (row, p) with token_kind[row][p + t - 1] == k of dz[row][p][o]   (kind: read / reference token)
 //     GS[t][j][o]        = sum over (row, p) of dz[row][p][o] * scalar_j[row][p + t - 1]             (q, strand, refmatch, varmatch, lenmask)

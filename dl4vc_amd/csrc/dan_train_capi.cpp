@@ -99,14 +99,13 @@ struct dan_trainer {
     // gradients of activations
     float *d_dhid1d = nullptr, *d_dhid1 = nullptr, *d_dhid0d = nullptr, *d_dhid0 = nullptr, *d_dfeatd = nullptr, *d_dfeat = nullptr;
     float *d_du = nullptr, *d_g[2] = {nullptr, nullptr}, *d_dn = nullptr, *d_dpool = nullptr, *d_dh = nullptr;
-    float *d_partial = nullptr, *d_bias_partial = nullptr, *d_hw_partial = nullptr, *d_emb_partial = nullptr;
+    float *d_partial = nullptr, *d_bias_partial = nullptr, *d_hw_partial = nullptr;
     float* d_clip = nullptr;
     float* d_dhw = nullptr;                                    // [layers][rows][HPAD]
     float* d_split_hw = nullptr;                               // split-K partials of the highway weight-gradient GEMM
     long long split_hw_floats = 0;
     float* d_split_ws = nullptr;                               // split-K partials of the forward FC GEMMs
     long long split_ws_floats = 0;
-    double* d_emb_bp = nullptr;
     double* d_l0tot = nullptr;                                  // layer 1's backward by bins: the totals (launch_l0_backward)
     float* d_l0tab = nullptr;                                   // layer 1's forward by table: rebuilt every step (launch_l0_train_tables)
     int last_B = 0;
@@ -415,7 +414,7 @@ int dan_train_finalize(dan_trainer_t* t) {
         (rc = talloc(t, &t->d_dn, rows * rowf, false)) || (rc = talloc(t, &t->d_dpool, (size_t)B * rowf, false))) return rc;
     if ((rc = talloc(t, &t->d_partial, (size_t)TRAIN_PARTIAL_WGS * 3 * CPAD * CPAD, false)) || (rc = talloc(t, &t->d_bias_partial, (size_t)2 * TRAIN_PARTIAL_WGS * CPAD, false)) ||
         (rc = talloc(t, &t->d_hw_partial, (size_t)8 * HPAD * L * HPAD + 64 * HPAD, false)) ||
-        (rc = talloc(t, &t->d_emb_bp, (rows / 64 + 2) * VOCAB * (2 * EMBED + 2))) || (rc = talloc(t, &t->d_l0tot, (size_t)L0_BINS_TOTALS)) || (rc = talloc(t, &t->d_l0tab, l0_tab_floats(L))) || (rc = talloc(t, &t->d_emb_partial, rows * VOCAB * (2 * EMBED + 2), false)) ||
+        (rc = talloc(t, &t->d_l0tot, (size_t)L0_BINS_TOTALS)) || (rc = talloc(t, &t->d_l0tab, l0_tab_floats(L))) ||
         (rc = talloc(t, &t->d_clip, 4))) return rc;
     if (H > 0) {
         t->split_hw_floats = (long long)8 * HPAD * L * HPAD;
@@ -789,19 +788,11 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
         {   // conv weight gradient: dz_l = (A dn + B a_l + C) * (a_l > 0);  gW[o][c][t] = sum_p dz[p][o] u_l[p + (t-1) d][c]
             WgradArgs w{};
             w.R = R; w.L = L; w.n_rows = n_rows; w.a1 = dn; w.a_stride = CPAD; w.a2 = t->d_a[l]; w.a_coef = t->d_coef_b; w.a_mask = 1;
-            if (l == 0) {
-                RowArgs e{};
-                fill_encode(e, t, B);
-                w.b_mode = 0; w.reads = e.reads; w.qual = e.qual; w.strand = e.strand; w.ref = e.ref; w.ref_mask = e.ref_mask; w.var_mask = e.var_mask;
-                w.emb = e.emb; w.pe = e.pe;
-            } else {
-                w.b_mode = 1; w.b1 = t->d_x[l - 1]; w.b_pool = t->d_pool[l];
-                if (t->lazy_x[l - 1]) { w.b1 = t->d_a[l - 1]; w.b_coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
-            }
-            w.taps = 3; w.dil = lp.dil; w.o_tiles = KGC; w.c_tiles = (l == 0) ? KG0 : KGC; w.partial = t->d_partial; w.bias_partial = t->d_bias_partial;
+            w.b_mode = 1; w.b1 = t->d_x[l - 1]; w.b_pool = t->d_pool[l];
+            if (t->lazy_x[l - 1]) { w.b1 = t->d_a[l - 1]; w.b_coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
+            w.taps = 3; w.dil = lp.dil; w.o_tiles = KGC; w.c_tiles = KGC; w.partial = t->d_partial; w.bias_partial = t->d_bias_partial;
             const int wgs = launch_train_wgrad(w, s);
-            launch_wgrad_reduce(t->d_partial, t->d_bias_partial, wgs, 3, CPAD, w.c_tiles * 16, lp.cout, lp.cin, l == 0 ? t->d_canon : nullptr,
-                                gp(t, lp.conv_w), gp(t, lp.conv_b), s);
+            launch_wgrad_reduce(t->d_partial, t->d_bias_partial, wgs, 3, CPAD, w.c_tiles * 16, lp.cout, lp.cin, nullptr, gp(t, lp.conv_w), gp(t, lp.conv_b), s);
         }
         {   // data gradient du_l = conv^T(dz_l)   (for layer 1: the gradient of the 48 encoded channels)
             RowArgs a{};
@@ -978,7 +969,8 @@ int64_t dan_train_get_tensor(dan_trainer_t* t, const char* name, float* dst, int
         else if (nm[4] == 'h' && t->d_h) { src = t->d_h + (size_t)l * rows * c.length * HPAD; n = rows * c.length * HPAD; }
     } else if (nm == "feature") { src = t->d_feat; n = (int64_t)B * t->F_stride; }
     else if (nm == "dfeature") { src = t->d_dfeat; n = (int64_t)B * t->F_stride; }
-    else if (nm == "du0") { src = t->d_du; n = rows * c.length * CPAD; }      // after a step: the gradient of the encoded input (canonical channel order)
+    else if (nm == "du0")      // (was: the gradient of the encoded input; layer 1's backward no longer forms it -- dan_train.hip, layer 1's backward by bins)
+        return failt(t, DAN_ERR_INVALID_ARG, "debug buffer 'du0' no longer exists: layer 1's gradients come from binned sums of dz_1, the encoded input's gradient is never formed");
     else if (nm == "logits") { src = t->d_logits; n = (int64_t)B * NHEAD; }
     else if (nm == "dlogits") { src = t->d_dlogits; n = (int64_t)B * NHEAD; }
     if (src) {

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Where the embedding gradient of a short-window training step goes wrong: the step's own du_0 (gradient of the encoded input,
+"""(HISTORICAL, round 5: the debug tap "du0" this script reads was removed when layer 1's backward went to binned sums -- the training fixtures and
+the float64-oracle tests pin the embedding gradient now; kept for the record of what was checked.)
+Where the embedding gradient of a short-window training step goes wrong: the step's own du_0 (gradient of the encoded input,
 tap "du0") is reduced on the host in float64 with the embedding rules (padding_idx 0, scale_grad_by_freq per lookup) and compared
 with (a) the device's grad:embeddings.weight -- isolates the three embedding kernels -- and (b) the float64 oracle's.
 Usage (GPU box): python tests/diagnostics/embedding_grad_short_window.py"""
