@@ -1,8 +1,7 @@
 // Diagnostic build of the conv-stack segment kernel with per-phase s_memtime stamps (never shipped,
 // never timed for throughput: stamps serialise the schedule -- read the SHARES, not the length).
-//   hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/seg_probe.hip -o /tmp/seg_probe && /tmp/seg_probe [l_begin l_end]
+//   hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/seg_probe.hip -o /tmp/seg_probe && /tmp/seg_probe [l_begin l_end [0 [wino [L [table 0|1]]]]]
 #include "../dl4vc_amd/csrc/dan_kernels.hip"
-#include "../dl4vc_amd/csrc/dan_kernels_bf16.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -45,15 +44,14 @@ int main(int argc, char** argv) {
     a.reads = a.qual = a.strand = a.ref = a.ref_mask = a.var_mask = d_u8;
     a.emb = d_emb; a.pe = d_pe; a.y = d_y; a.pool = l_begin ? d_pool : nullptr; a.h = d_h; a.h_layer_stride = (long long)hls;
     a.tap = nullptr; a.tap_layer = -1; a.wino = wino;
-    char* d_wl16;
-    CK(hipMalloc(&d_wl16, (size_t)layers * W16_LAYER_BYTES));
-    CK(hipMemset(d_wl16, 0, (size_t)layers * W16_LAYER_BYTES));
-    Segment16Args q{};
-    q.wl = d_wl16; q.l_begin = a.l_begin; q.l_end = a.l_end; q.n_layers = a.n_layers; q.dil_mid = 2; q.dil_final = 2;
-    q.res_mask = a.res_mask; q.has_hw = 1; q.R = R; q.L = L; q.reads = q.qual = q.strand = q.ref = q.ref_mask = q.var_mask = d_u8;
-    q.emb = d_emb; q.pe = d_pe; q.y = d_y; q.pool = a.pool; q.h = d_h; q.h_layer_stride = a.h_layer_stride; q.tap = nullptr; q.tap_layer = -1;
+    // (precision != 0 selected the round-3 bf16 kernel, deleted in round 4: the bf16 families have probes of their own, segx / segp)
+    if (precision != 0) { printf("seg_probe covers the fp32 kernel only: use tools/segx_probe.hip / tools/segp_probe.hip\n"); return 1; }
+    // layer 1 by table (dan_kernels.h L0_*): an all-zero table exercises the walk's instruction stream
+    float* d_l0;
+    CK(hipMalloc(&d_l0, l0_tab_floats(L) * 4)); CK(hipMemset(d_l0, 0, l0_tab_floats(L) * 4));
+    a.l0_tab = argc > 6 && atoi(argv[6]) == 0 ? nullptr : d_l0;
     for (int rep = 0; rep < 3; ++rep) {
-        if (precision == 0) launch_segment(a, sites, 0, 0); else launch_segment16(q, sites, precision, 0, 0);
+        launch_segment(a, sites, 0, 0);
         CK(hipDeviceSynchronize());
     }
     std::vector<unsigned long long> st(nst);
