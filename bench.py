@@ -3,8 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (dan_forward_device: encode -> conv stack -> read pooling ->
-highway -> FC -> heads -> softmax) over one synthetic batch of 65 536 candidate sites x 64 reads x 201
+One "step" = one pass of the hot path (dan_forward_device: token planes -> conv stack (fp32: layer 1 summed from
+tables) -> read pooling -> highway -> FC -> heads -> softmax) over one synthetic batch of 65 536 candidate sites x 64 reads x 201
 columns per GPU, production network (7 x 128-channel dilated conv, FC 65 792 -> 1024 -> 256), fp32,
 seeded random weights (no checkpoint or HG002 data offline).  Inputs are resident in HBM before the
 timed region.  For N > 1 the driver launches one rank per GPU with torch.distributed.run; sites shard
