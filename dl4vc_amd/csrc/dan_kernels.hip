@@ -469,18 +469,30 @@ next_row:                                                   // (PERSIST only: ba
             asm volatile("" : "+v"(wp));       // keeps everything derived from it (addresses, masks) out of the GEMM's live set
             xq = xs + (HALO + wp) * LDS_S;
             // output transform, then ReLU and the folded BatchNorm (model.py:749-751); positions >= L stay zero
+            // (on register pairs: packed fp32 adds and multiply-adds, the same operations in the same order per element.  Columns
+            // at or past L are not masked here: they are never stored -- `wl` below -- and their LDS rows keep the prologue's zeros.)
             const v4f sc = *(const v4f*)(lc + CST_SCALE + chw), sh = *(const v4f*)(lc + CST_SHIFT + chw);
+            const v2f sc_lo = {sc[0], sc[1]}, sc_hi = {sc[2], sc[3]}, sh_lo = {sh[0], sh[1]}, sh_hi = {sh[2], sh[3]};
+            auto half = [](v4f v, int h) { return (v2f){v[2 * h], v[2 * h + 1]}; };
+            v2f neg1 = {-1.f, -1.f};
+            asm volatile("" : "+v"(neg1));                 // (opaque, or the subtraction comes back)
+            auto act = [](v2f y, v2f s, v2f t) {
+                const v2f r = {relu1(y[0]), relu1(y[1])};
+                return __builtin_elementwise_fma(r, s, t);
+            };
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                const v4f y0 = acc[m][0] + acc[m][1] + acc[m][2], y1 = acc[m][1] - acc[m][2] - acc[m][3];
-                const int p = wp + 4 * m;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    out[m][0][j] = (p < L) ? relu1(y0[j]) * sc[j] + sh[j] : 0.f;
-                    out[m][1][j] = (p + 2 < L) ? relu1(y1[j]) * sc[j] + sh[j] : 0.f;
-                }
+                const v2f y0l = half(acc[m][0], 0) + half(acc[m][1], 0) + half(acc[m][2], 0), y0h = half(acc[m][0], 1) + half(acc[m][1], 1) + half(acc[m][2], 1);
+                // (a - b as fma(b, -1, a): exact, and a packed instruction -- hipcc splits a subtraction of pairs into two scalar ones)
+                const v2f y1l = __builtin_elementwise_fma(half(acc[m][3], 0), neg1, __builtin_elementwise_fma(half(acc[m][2], 0), neg1, half(acc[m][1], 0)));
+                const v2f y1h = __builtin_elementwise_fma(half(acc[m][3], 1), neg1, __builtin_elementwise_fma(half(acc[m][2], 1), neg1, half(acc[m][1], 1)));
+                const v2f o0l = act(y0l, sc_lo, sh_lo), o0h = act(y0h, sc_hi, sh_hi), o1l = act(y1l, sc_lo, sh_lo), o1h = act(y1h, sc_hi, sh_hi);
+                out[m][0] = (v4f){o0l[0], o0l[1], o0h[0], o0h[1]};
+                out[m][1] = (v4f){o1l[0], o1l[1], o1h[0], o1h[1]};
             }
         }
+        int wl = min(wlim, L);                           // columns this lane stores: its tiling's, inside the window
+        asm volatile("" : "+v"(wl));                    // (opaque: hipcc, knowing p < wl implies p < L, merges the residual's two loads below into one through a selected POINTER and fails on the LDS one's cast)
         // the accumulators fill the register file through the GEMM and the output transform: the later stages' first
         // fragments are requested only now (the barriers, the write-back and the residual GEMM cover their latency)
         __builtin_amdgcn_sched_barrier(0);
@@ -504,19 +516,35 @@ next_row:                                                   // (PERSIST only: ba
         STAMP(sb + 3);
         if (residual) {
             const v4f bres = *(const v4f*)(lc + CST_BRES + chw);
+            // the 1x1 GEMM's input (this layer's BatchNorm output) goes into the image, the layer input it replaces seeds the accumulators.
+            // Two loops under one uniform branch (as one loop with the choice inside, every cell carried both paths and their masks).
+            if (from_global) {
 #pragma unroll
-            for (int m = 0; m < MW; ++m)
+                for (int m = 0; m < MW; ++m)
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const int p = wp + 4 * m + 2 * o;
-                    if (p < wlim) {
-                        v4f* cell = (v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw);
-                        // (uniform base + 32-bit lane offset: one VGPR per address instead of a 64-bit pair)
-                        const v4f old = from_global ? ((p < L) ? *(const v4f*)((const char*)yrow + (unsigned)(p * CPAD + chw) * 4u) : splat(0.f)) : *cell;
-                        *cell = out[m][o];
-                        out[m][o] = old + bres;
+                    for (int o = 0; o < 2; ++o) {
+                        const int p = wp + 4 * m + 2 * o;
+                        if (p < wl) {
+                            // (uniform base + 32-bit lane offset: one VGPR per address instead of a 64-bit pair)
+                            const v4f old = *(const v4f*)((const char*)yrow + (unsigned)(p * CPAD + chw) * 4u);
+                            *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = out[m][o];
+                            out[m][o] = old + bres;
+                        }
                     }
-                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const int p = wp + 4 * m + 2 * o;
+                        if (p < wl) {
+                            v4f* cell = (v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw);
+                            const v4f old = *cell;
+                            *cell = out[m][o];
+                            out[m][o] = old + bres;
+                        }
+                    }
+            }
             __syncthreads();
             STAMP(sb + 4);
             gemm1x1_wino(out, xq + kk * 4, w_r1, pre_r1);
@@ -532,7 +560,7 @@ next_row:                                                   // (PERSIST only: ba
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int p = wp + 4 * m + 2 * o;
-                    if (p < wlim) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = (p < L) ? out[m][o] : splat(0.f);
+                    if (p < wl) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = out[m][o];
                 }
         } else {
 #pragma unroll
@@ -540,7 +568,7 @@ next_row:                                                   // (PERSIST only: ba
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int p = wp + 4 * m + 2 * o;
-                    if (p < wlim) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = out[m][o];
+                    if (p < wl) *(v4f*)(xq + (4 * m + 2 * o) * LDS_S + chw) = out[m][o];
                 }
         }
         layer_tail(l, lc, false);
