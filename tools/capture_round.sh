@@ -49,8 +49,9 @@ timeout -k 10 60 /tmp/segp_probe.bin 2 7 301 > "$out/segp_probe_segment2.txt" 2>
 hipcc -O3 --offload-arch=gfx950 -DDAN_STAMPS tools/segx_probe.hip -o /tmp/segx_probe.bin 2> /dev/null
 timeout -k 10 60 /tmp/segx_probe.bin 0 2 201 64 > "$out/segx_probe_segment1.txt" 2>&1
 timeout -k 10 60 /tmp/segx_probe.bin 2 7 201 64 > "$out/segx_probe_segment2.txt" 2>&1
-hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_bf16_feed.hip -o /tmp/mfma_bf16_feed.bin 2> /dev/null
-hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_alone.hip -o /tmp/gemm_p_alone.bin 2> /dev/null
-hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_lone.hip -o /tmp/gemm_p_lone.bin 2> /dev/null
-( timeout -k 10 60 /tmp/mfma_bf16_feed.bin && timeout -k 10 60 /tmp/gemm_p_alone.bin && timeout -k 10 60 /tmp/gemm_p_lone.bin ) > "$out/ubench_mfma_bf16.txt" 2>&1
+hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_bf16_feed.hip -o /tmp/mfma_bf16_feed.bin 2> /dev/null || true
+hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_alone.hip -o /tmp/gemm_p_alone.bin 2> /dev/null || true
+hipcc -O3 --offload-arch=gfx950 tools/ubench/gemm_p_lone.hip -o /tmp/gemm_p_lone.bin 2> /dev/null || true
+# (the round-3 / round-4 microbenchmarks: kept for reference, not part of a round's record any more -- a failure here does not fail the capture)
+( timeout -k 10 60 /tmp/mfma_bf16_feed.bin && timeout -k 10 60 /tmp/gemm_p_alone.bin && timeout -k 10 60 /tmp/gemm_p_lone.bin ) > "$out/ubench_mfma_bf16.txt" 2>&1 || echo "ubench skipped"
 echo captured
