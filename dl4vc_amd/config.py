@@ -17,9 +17,10 @@ NUM_SINGLE_READS = 100
 MAX_READS = 100
 MIN_RESIDUAL_LAYER = 2
 MAX_LAYERS = 16       # capacity of the C-ABI config struct (include/dl4vc_dan.h)
+L0_MAX_LAYERS = 12    # csrc/dan_kernels.h: layer 1 is summed from tables when the first segment has at most this many layers
 
 PRECISION_F32 = 0     # v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (parity path, the default)
-PRECISION_BF16X3 = 1  # split-bf16: hi+lo operands, three bf16 MFMAs per product, fp32 accumulate (L <= 208)
+PRECISION_BF16X3 = 1  # split-bf16: hi+lo operands, three bf16 MFMAs per product, fp32 accumulate (L <= 304)
 PRECISION_BF16 = 2    # plain bf16 operands, fp32 accumulate (BASELINE config 5: 128 reads x 301 bp; L <= 304)
 
 
@@ -121,9 +122,12 @@ class DanConfig:
             for l in range(2, self.layers + 1):
                 cin, cout, _ = self.layer_dims(l)
                 total -= cin * cout
-        if self.precision == PRECISION_F32:
+        first_segment = min(self.pool_layers) if self.pool_layers else self.layers
+        if self.precision == PRECISION_F32 and first_segment <= L0_MAX_LAYERS:
             # the fp32 path computes layer 1 from tables on the vector ALUs (csrc/dan_kernels.h L0_*): its 3 * cin * cout
-            # multiply-accumulates per position are algorithmic work but issue no MFMA
+            # multiply-accumulates per position are algorithmic work but issue no MFMA.  (The kernel keeps the GEMM form when its
+            # first segment has more than L0_MAX_LAYERS layers -- csrc/dan_kernels.hip `l0_lookup` -- and, for that one forward,
+            # when a debug tap sits on the encoded input; neither occurs in a measured run.)
             cin, cout, _ = self.layer_dims(1)
             total -= 3 * cin * cout
         return total

@@ -718,11 +718,17 @@ void dan_destroy(dan_t* h) {
     delete h;
 }
 
-// chunk_ready (may be null): event k is waited for on the stream in front of the k-th conv chunk's first launch -- the asynchronous
-// host path uploads a macro-batch chunk by chunk and the forward of chunk 0 starts when chunk 0 has arrived
+// feed (may be null): called in front of the k-th conv chunk's first launch; it brings that chunk's inputs onto the device (on a
+// stream of its own) and hands back the event the compute stream waits for.  The asynchronous host path uploads a macro-batch
+// chunk by chunk THROUGH this: chunk k's launches are queued before the host touches chunk k + 1, so the forward of chunk 0 starts
+// after one chunk's staging and the staging of chunk k + 1 runs under chunk k's kernels.
+struct ChunkFeed {
+    int (*fn)(void* ctx, int64_t first_site, int n_sites, int64_t k, hipEvent_t* ready);
+    void* ctx;
+};
 static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
                                const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
-                               float* vt_logits, float* vt_prob, float* bp, float* aux, void* stream, const hipEvent_t* chunk_ready);
+                               float* vt_logits, float* vt_prob, float* bp, float* aux, void* stream, const ChunkFeed* feed);
 
 int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
                        const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
@@ -732,7 +738,7 @@ int dan_forward_device(dan_t* h, const uint8_t* reads, const uint8_t* qual, cons
 
 static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
                                const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
-                               float* vt_logits, float* vt_prob, float* bp, float* aux, void* stream, const hipEvent_t* chunk_ready) {
+                               float* vt_logits, float* vt_prob, float* bp, float* aux, void* stream, const ChunkFeed* feed) {
     if (!h) return DAN_ERR_INVALID_ARG;
     if (!h->finalized) return fail(h, DAN_ERR_STATE, "dan_forward before dan_finalize");
     if (n_sites < 0) return fail(h, DAN_ERR_INVALID_ARG, "negative site count");
@@ -749,7 +755,11 @@ static int forward_device_impl(dan_t* h, const uint8_t* reads, const uint8_t* qu
         for (int c0 = 0; c0 < nb; c0 += h->chunk) {
             const int ns = std::min(h->chunk, nb - c0);
             const int64_t g0 = mb + c0;                      // first site of the chunk in the caller's arrays
-            if (chunk_ready) HIPCHK(h, hipStreamWaitEvent(s, chunk_ready[g0 / h->chunk], 0));
+            if (feed) {
+                hipEvent_t ready;
+                int rcf = feed->fn(feed->ctx, g0, ns, g0 / h->chunk, &ready); if (rcf) return rcf;
+                HIPCHK(h, hipStreamWaitEvent(s, ready, 0));
+            }
             if (h->d_rowsrc) {
                 EventPair evm{};
                 int rcm = prof_begin(h, "row_map", s, &evm); if (rcm) return rcm;
@@ -928,6 +938,58 @@ static int async_init(dan_handle* h) {
     return DAN_OK;
 }
 
+// One conv chunk of an asynchronous batch: caller's pageable planes -> the slot's pinned mirror -> the device, on the copy stream.
+// The mirror is filled by up to four threads (one core moves pageable memory at 5-10 GB/s: 118 MB per chunk at 128 x 301).  Nothing
+// here allocates: a fixed table of pieces and of threads, so that no std::bad_alloc can leave through the C ABI; a thread that
+// cannot be started (std::system_error) leaves its pieces to the calling thread.
+struct AsyncStage {
+    dan_handle* h; dan_handle::Slot* sl;
+    const uint8_t* src[6]; size_t off[6]; size_t per_site[6];
+};
+
+static int stage_chunk(void* ctx, int64_t first_site, int n_sites, int64_t k, hipEvent_t* ready) {
+    AsyncStage& st = *static_cast<AsyncStage*>(ctx);
+    dan_handle* h = st.h;
+    dan_handle::Slot& sl = *st.sl;
+    if (k < 0 || (size_t)k >= sl.ev_slice.size()) return fail(h, DAN_ERR_STATE, "chunk %lld outside the slot's event table", (long long)k);
+    const size_t s0 = (size_t)first_site, ns = (size_t)n_sites;
+    constexpr int MAX_THR = 4;
+    struct Piece { uint8_t* dst; const uint8_t* src; size_t n; };
+    Piece pieces[3 * MAX_THR + 3];
+    int n_pieces = 0;
+    size_t total = 0;
+    for (int i = 0; i < 6; ++i) total += ns * st.per_site[i];
+    const int n_thr = total >= ((size_t)32 << 20) ? MAX_THR : 1;
+    for (int i = 0; i < 6; ++i) {
+        const size_t o = st.off[i] + s0 * st.per_site[i], n = ns * st.per_site[i];
+        const int parts = (i < 3) ? n_thr : 1;                   // the three read planes are the bytes; the site planes ride with thread 0
+        for (int t = 0; t < parts; ++t) {
+            const size_t a0 = n * t / parts, a1 = n * (t + 1) / parts;
+            pieces[n_pieces++] = {sl.pin_in + o + a0, st.src[i] + s0 * st.per_site[i] + a0, a1 - a0};
+        }
+    }
+    // pieces 0 .. 3 n_thr - 1 are the read planes' parts (piece j belongs to thread j % n_thr), the rest the site planes
+    std::thread workers[MAX_THR];
+    bool started[MAX_THR] = {false, false, false, false};
+    const Piece* pc = pieces;
+    for (int t = 1; t < n_thr; ++t) {
+        try {
+            workers[t] = std::thread([pc, t, n_thr] { for (int j = t; j < 3 * n_thr; j += n_thr) memcpy(pc[j].dst, pc[j].src, pc[j].n); });
+            started[t] = true;
+        } catch (...) {}
+    }
+    for (int j = 0; j < n_pieces; ++j)
+        if (j >= 3 * n_thr || !started[j % n_thr]) memcpy(pieces[j].dst, pieces[j].src, pieces[j].n);
+    for (int t = 1; t < n_thr; ++t) if (started[t]) workers[t].join();
+    for (int i = 0; i < 6; ++i) {
+        const size_t o = st.off[i] + s0 * st.per_site[i];
+        HIPCHK(h, hipMemcpyAsync(sl.dev_in + o, sl.pin_in + o, ns * st.per_site[i], hipMemcpyHostToDevice, h->s_h2d));
+    }
+    HIPCHK(h, hipEventRecord(sl.ev_slice[(size_t)k], h->s_h2d));
+    *ready = sl.ev_slice[(size_t)k];
+    return DAN_OK;
+}
+
 int dan_forward_async(dan_t* h, const uint8_t* reads, const uint8_t* qual, const uint8_t* strand, const uint8_t* ref,
                       const uint8_t* ref_mask, const uint8_t* var_mask, int64_t n_sites, float* bin_logits,
                       float* vt_logits, float* vt_prob, float* bp, float* aux, int64_t* ticket) {
@@ -943,55 +1005,19 @@ int dan_forward_async(dan_t* h, const uint8_t* reads, const uint8_t* qual, const
     if (sl.ticket >= 0)
         return fail(h, DAN_ERR_STATE, "two batches are already in flight: dan_wait(%lld) first", (long long)sl.ticket);
     const size_t nb = (size_t)n_sites, rl = (size_t)c.reads * c.length, L = c.length;
-    const size_t in_bytes = nb * (3 * rl + 3 * L);
-    const uint8_t* src[6] = {reads, qual, strand, ref, ref_mask, var_mask};
-    const size_t off[7] = {0, nb * rl, 2 * nb * rl, 3 * nb * rl, 3 * nb * rl + nb * L, 3 * nb * rl + 2 * nb * L, in_bytes};
-    const size_t per_site[6] = {rl, rl, rl, L, L, L};
     if (nb) {
-        // The batch goes up CHUNK BY CHUNK (the conv stack's own unit): chunk k is copied into the pinned mirror -- by up to four
-        // threads: one core moves pageable memory at 5-10 GB/s, 474 MB of a 4096-site batch at 128 x 301 were 60 ms in front of the
-        // first launch -- its six plane ranges are sent on the copy stream and an event is recorded; the forward waits for event k in
-        // front of chunk k's first launch, so it starts after one chunk's staging instead of the whole batch's, and the staging
-        // of chunk k + 1 runs under the upload of chunk k.  (Device layout unchanged: plane-major over the batch.)
-        const size_t chunk = (size_t)h->chunk;
-        for (size_t s0 = 0, k = 0; s0 < nb; s0 += chunk, ++k) {
-            const size_t ns = std::min(chunk, nb - s0);
-            struct Piece { uint8_t* dst; const uint8_t* src; size_t n; };
-            std::vector<Piece> pieces;
-            const size_t total = ns * (3 * rl + 3 * L);
-            const int n_thr = total >= ((size_t)32 << 20) ? 4 : 1;
-            for (int i = 0; i < 6; ++i) {
-                const size_t o = off[i] + s0 * per_site[i], n = ns * per_site[i];
-                const int parts = (i < 3) ? n_thr : 1;           // the three read planes are the bytes; the site planes ride with thread 0
-                for (int t = 0; t < parts; ++t) {
-                    const size_t a0 = n * t / parts, a1 = n * (t + 1) / parts;
-                    pieces.push_back({sl.pin_in + o + a0, src[i] + s0 * per_site[i] + a0, a1 - a0});
-                }
-            }
-            // (a thread that cannot be started -- std::system_error -- must not leave through the C ABI: its pieces are copied here)
-            std::vector<std::thread> pool;
-            std::vector<char> started((size_t)n_thr, 0);
-            for (int t = 1; t < n_thr; ++t) {
-                try {
-                    pool.emplace_back([&pieces, t, n_thr] { for (size_t j = t; j < 3 * (size_t)n_thr; j += n_thr) memcpy(pieces[j].dst, pieces[j].src, pieces[j].n); });
-                    started[t] = 1;
-                } catch (...) {}
-            }
-            for (size_t j = 0; j < pieces.size(); ++j)
-                if (j >= 3 * (size_t)n_thr || !started[j % n_thr]) memcpy(pieces[j].dst, pieces[j].src, pieces[j].n);
-            for (auto& th : pool) th.join();
-            for (int i = 0; i < 6; ++i) {
-                const size_t o = off[i] + s0 * per_site[i];
-                HIPCHK(h, hipMemcpyAsync(sl.dev_in + o, sl.pin_in + o, ns * per_site[i], hipMemcpyHostToDevice, h->s_h2d));
-            }
-            HIPCHK(h, hipEventRecord(sl.ev_slice[k], h->s_h2d));
-        }
-        HIPCHK(h, hipEventRecord(sl.ev_h2d, h->s_h2d));
+        AsyncStage st{};
+        st.h = h; st.sl = &sl;
+        const uint8_t* src[6] = {reads, qual, strand, ref, ref_mask, var_mask};
+        const size_t off[7] = {0, nb * rl, 2 * nb * rl, 3 * nb * rl, 3 * nb * rl + nb * L, 3 * nb * rl + 2 * nb * L, nb * (3 * rl + 3 * L)};
+        for (int i = 0; i < 6; ++i) { st.src[i] = src[i]; st.off[i] = off[i]; st.per_site[i] = i < 3 ? rl : L; }
+        const ChunkFeed feed{stage_chunk, &st};
         uint8_t* d = sl.dev_in;
         float *o_bin = sl.dev_out, *o_vt = o_bin + nb * 2, *o_p = o_vt + nb * 3, *o_bp = o_p + nb * 3, *o_aux = o_bp + nb;
         int rc = forward_device_impl(h, d + off[0], d + off[1], d + off[2], d + off[3], d + off[4], d + off[5], n_sites, o_bin, o_vt,
-                                     o_p, o_bp, o_aux, (void*)h->s_comp, sl.ev_slice.data());
+                                     o_p, o_bp, o_aux, (void*)h->s_comp, &feed);
         if (rc) return rc;
+        HIPCHK(h, hipEventRecord(sl.ev_h2d, h->s_h2d));
         HIPCHK(h, hipEventRecord(sl.ev_comp, h->s_comp));
         HIPCHK(h, hipStreamWaitEvent(h->s_d2h, sl.ev_comp, 0));
         HIPCHK(h, hipMemcpyAsync(sl.pin_out, sl.dev_out, nb * 31 * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));

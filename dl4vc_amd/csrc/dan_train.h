@@ -145,7 +145,8 @@ void launch_highway_wgrad(const float* dfeat, const float* feat, long long fs, i
 // a: R, L, n_rows, a1, a2, a_coef, a_mask, the six token planes, emb, pe, partial (TRAIN_PARTIAL_WGS slices of 3 CPAD CPAD floats);
 // tot: L0B_FLOATS doubles (device scratch); w1: conv1's weights [n_out][n_in][3]; canon: reference channel -> canonical channel
 constexpr int L0_BINS_TOTALS = 208 * 128 + 2 * 3 * 10 * 128 + 3 * 5 * 128 + 32;
-void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
+int l0_bins_lds_bytes();
+int launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
                         float* g_b, float* g_emb, hipStream_t s);
 // Layer 1's forward by table (the inference walk of dan_kernels.h L0_*, tables rebuilt from the step's weights): tab = l0_tab_floats(L)
 // floats; inv: canonical channel -> reference channel or -1.  The forward writes a_1 = relu(conv1 + bias) [row][L][CPAD] and, if stats,

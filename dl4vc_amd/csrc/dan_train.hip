@@ -2129,15 +2129,19 @@ __global__ __launch_bounds__(256) void l0_grads_kernel(const double* __restrict_
 
 int l0_bins_lds_bytes() { return ((MPOS + 2) * L0B_DZ_S + 2 * MPOS * L0B_A) * (int)sizeof(float); }
 
-void launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
-                        float* g_b, float* g_emb, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)l0_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l0_bins_lds_bytes()); attr = true; }
+// Returns 0, or the hipError_t of the attribute call when the device refuses the kernel's dynamic LDS size (nothing is launched then).
+// The attribute belongs to (function, device): set on every call -- one driver table lookup -- rather than once per process, which
+// would leave a second device of the same process without it.
+int launch_l0_backward(const WgradArgs& a, int n_sites, double* tot, const float* w1, const int* canon, int n_out, int n_in, float* g_w,
+                       float* g_b, float* g_emb, hipStream_t s) {
+    const hipError_t e = hipFuncSetAttribute((const void*)l0_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l0_bins_lds_bytes());
+    if (e != hipSuccess) return (int)e;
     const int wgs = a.n_rows < TRAIN_PARTIAL_WGS ? a.n_rows : TRAIN_PARTIAL_WGS;
     hipLaunchKernelGGL(l0_bins_kernel, dim3(wgs), dim3(512), l0_bins_lds_bytes(), s, a, n_sites);
     hipLaunchKernelGGL(l0_bins_reduce_kernel, dim3((L0B_FLOATS + 255) / 256), dim3(256), 0, s, a.partial, wgs, tot);
     const int total = 3 * n_out * n_in + n_out + VOCAB * EMBED;
     hipLaunchKernelGGL(l0_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tot, a.emb, a.pe, w1, canon, a.L, n_out, n_in, g_w, g_b, g_emb);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -657,7 +657,7 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             if (lp.residual && t->lazy_x[l - 1]) { a.add1 = t->d_a[l - 1]; a.add1_coef = t->d_coef_f + (size_t)(l - 1) * 3 * CPAD; }
             a.out1 = t->d_x[l];                              // (nullptr for a lazy layer: the launch then only writes h_l)
             if (H > 0) { a.w2 = t->pk_bot_f[l]; a.bias2 = bias + 2 * CPAD; a.out2 = t->d_h + (size_t)l * n_rows * L * HPAD; }
-            launch_train_row(a, n_rows, s, stat_cap);
+            if ((rc = check_row_launch(t, launch_train_row(a, n_rows, s, stat_cap), "BatchNorm-apply / residual / bottleneck", l))) return rc;
         }
         if (pool_after(c, l + 1)) launch_read_mean(t->d_x[l], t->d_pool[l + 1], B, R, L, nullptr, s);
     }
@@ -781,7 +781,8 @@ int dan_train_backward_begin(dan_trainer_t* t, const uint8_t* reads, const uint8
             fill_encode(e, t, B);
             w.reads = e.reads; w.qual = e.qual; w.strand = e.strand; w.ref = e.ref; w.ref_mask = e.ref_mask; w.var_mask = e.var_mask;
             w.emb = e.emb; w.pe = e.pe; w.partial = t->d_partial;
-            launch_l0_backward(w, B, t->d_l0tot, pp(t, lp.conv_w), t->d_canon, lp.cout, lp.cin, gp(t, lp.conv_w), gp(t, lp.conv_b), gp(t, t->p_emb), s);
+            const int e0 = launch_l0_backward(w, B, t->d_l0tot, pp(t, lp.conv_w), t->d_canon, lp.cout, lp.cin, gp(t, lp.conv_w), gp(t, lp.conv_b), gp(t, t->p_emb), s);
+            if (e0) return failt(t, DAN_ERR_HIP, "layer 1's backward: the device refuses %d B of dynamic LDS for l0_bins_kernel: %s", l0_bins_lds_bytes(), hipGetErrorString((hipError_t)e0));
             cur ^= 1;
             continue;
         }

@@ -55,7 +55,8 @@ typedef struct dan_config {
     int32_t bottleneck;       /* bottleneck_channels == bottleneck_linear_outputs, 0 = no highway */
     int32_t fc_sizes[2];      /* layer_sizes              model.py:35   */
     int32_t precision;        /* 0 = fp32 MFMA (parity path); 1 = bf16x3 split (hi+lo bf16, 3 MFMAs per
-                               * product, L <= 208); 2 = plain bf16 (L <= 304, BASELINE config 5)   */
+                               * product, L <= 304: two units per read above 208 columns, like precision 0); 2 = plain bf16
+                               * (L <= 304, BASELINE config 5)                                      */
     int32_t device_id;        /* HIP device ordinal                                               */
     int32_t max_batch;        /* sites per FC macro-batch (0 = 4096)                              */
     int32_t chunk_sites;      /* sites per conv-stack chunk (0 = largest power of two whose y + h fit 48 GB and a third of the

@@ -234,7 +234,11 @@ def dan_forward_oracle(state_dict, cfg, reads, qual, strand, ref, ref_mask, var_
         if taps:
             out["conv%d" % l] = x.numpy().copy()
         if l in spec.pool_layers:
-            pool = x.mean(dim=2, keepdim=True)                   # AvgPool2d((MAX_READS,1)) over all R rows, model.py:772
+            # AvgPool2d((MAX_READS,1), ceil_mode) over all R rows, model.py:194,772: the same pooling op as the reference -- rows
+            # summed IN ORDER, then divided by the rows present -- and not x.mean(dim=2), whose pairwise sum differs in the last bit:
+            # harmless in fp32, but in the bf16 modes a last-bit difference of y + pool flips bf16 roundings (325 of 1.8 M elements
+            # at 128 reads x 301 columns, each a 1e-3-of-max change downstream: found by the R > 100 fixtures of round 6)
+            pool = F.avg_pool2d(x, (R, 1))
             if taps:
                 out["pool%d" % l] = pool.numpy().copy()
         if spec.bottleneck > 0:
@@ -247,7 +251,7 @@ def dan_forward_oracle(state_dict, cfg, reads, qual, strand, ref, ref_mask, var_
             if taps:
                 out["hw%d" % l] = hw.numpy().copy()
     mx = x.max(dim=2, keepdim=True).values                       # model.py:825
-    av = x.mean(dim=2, keepdim=True)                             # model.py:826
+    av = F.avg_pool2d(x, (R, 1))                                 # model.py:304,826 (in-order sum, as above)
     feat = torch.cat((mx, av), dim=1).reshape(B, -1)             # model.py:833,839
     if spec.bottleneck > 0:
         feat = torch.cat((feat, F.relu(torch.cat(hws, dim=1))), dim=1)   # model.py:854,859,912

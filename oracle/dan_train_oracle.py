@@ -86,9 +86,23 @@ def focal_soft_bce(logits: torch.Tensor, target: torch.Tensor, weight: torch.Ten
 
 
 def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor, dropout_masks: Optional[Sequence],
-                  hp: TrainHyper, taps: Optional[dict] = None):
-    """Train-mode forward from the encoded input ``x`` (B,Cin,R,L).  Returns (outputs dict, {layer: (mean, biased var)})."""
+                  hp: TrainHyper, taps: Optional[dict] = None, forced: Optional[dict] = None):
+    """Train-mode forward from the encoded input ``x`` (B,Cin,R,L).  Returns (outputs dict, {layer: (mean, biased var)}).
+
+    ``forced`` (tests only): the DISCRETE decisions of another evaluation of the same step, imposed on this one -- "relu<l>" /
+    "hrelu<l>": bool (B,C,R,L) masks used in place of the conv / bottleneck ReLU's own sign test (x * mask: the same function and
+    the same derivative wherever the two agree), "argmax": int (B,C,L), the read that takes the final max.  A ReLU input or a
+    top-1 / top-2 gap within an fp32 rounding error of its edge is decided either way by correct fp32 evaluations, and one such
+    decision moves gradient tensors by up to 2e-2 of their max; with the device's decisions imposed, the float64 result is the exact
+    gradient of the network the device differentiated and the comparison needs no loose bar."""
     B, _, R, L = x.shape
+    forced = forced or {}
+
+    def relu(t, key):
+        if key in forced:
+            return t * torch.as_tensor(np.asarray(forced[key])).to(t.dtype)
+        return F.relu(t)
+
     pool = None
     hws = []
     stats = {}
@@ -101,7 +115,7 @@ def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor
                      padding=(0, dil), dilation=(1, dil))
         if taps is not None:
             taps["pre%d" % l] = x.detach().numpy().copy()           # (the ReLU's input: which mask decisions sit on a rounding error)
-        x = F.relu(x)                                                # model.py:749
+        x = relu(x, "relu%d" % l)                                    # model.py:749
         if spec.use_bn:                                              # training-mode BN after the ReLU, model.py:750-751
             p = "bn1D_layers.%d." % (l - 1)
             mu = x.mean(dim=(0, 2, 3))
@@ -120,11 +134,14 @@ def train_forward(sd: Dict[str, torch.Tensor], spec: OracleSpec, x: torch.Tensor
             h = F.conv2d(x, sd["conv1D_bottleneck_layers.%d.weight" % (l - 1)], sd["conv1D_bottleneck_layers.%d.bias" % (l - 1)])
             if taps is not None:
                 taps["hpre%d" % l] = h.detach().numpy().copy()
-            h = F.relu(h)
+            h = relu(h, "hrelu%d" % l)
             hw = F.conv2d(h, sd["conv1D_compression_layers.%d.weight" % (l - 1)],
                           sd["conv1D_compression_layers.%d.bias" % (l - 1)])
             hws.append(hw.squeeze(3).reshape(B, -1))
-    mx = x.max(dim=2, keepdim=True).values
+    if "argmax" in forced:
+        mx = torch.gather(x, 2, torch.as_tensor(np.asarray(forced["argmax"])).long()[:, :, None, :])
+    else:
+        mx = x.max(dim=2, keepdim=True).values
     av = x.mean(dim=2, keepdim=True)
     feat = torch.cat((mx, av), dim=1).reshape(B, -1)
     if spec.bottleneck > 0:
@@ -208,7 +225,8 @@ def trainable(name: str) -> bool:
 
 
 def train_step_oracle(state_dict, cfg, planes, targets, hp: TrainHyper = TrainHyper(), dropout_masks=None,
-                      adam_state: Optional[dict] = None, step: int = 1, dtype=torch.float32, taps: bool = False):
+                      adam_state: Optional[dict] = None, step: int = 1, dtype=torch.float32, taps: bool = False,
+                      forced: Optional[dict] = None):
     """One optimisation step.  Returns a dict of numpy arrays:
       loss terms ('loss','bin','vt','af','cov','vb','vr'), 'bin_close','vt_close' (B,) bool, outputs ('out:<name>'),
       'grad:<param>' (before clipping), 'grad_norm', 'clip_coef', 'new:<tensor>' (parameters after Adam, BN running stats
@@ -233,7 +251,7 @@ def train_step_oracle(state_dict, cfg, planes, targets, hp: TrainHyper = TrainHy
     emb = torch.cat((r_emb, f_emb), dim=3).permute(0, 3, 1, 2)
     x = torch.cat((emb, x_const[:, 2 * spec.embed_dim:]), dim=1)
     tp = {} if taps else None
-    out, stats = train_forward(live, spec, x, dropout_masks, hp, tp)
+    out, stats = train_forward(live, spec, x, dropout_masks, hp, tp, forced)      # (``forced``: see train_forward; tests only)
     ls = losses(out, targets, hp)
     ls["loss"].backward()
     res: Dict[str, np.ndarray] = {}

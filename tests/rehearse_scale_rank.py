@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
+from dl4vc_amd.capi import tree_source_hash  # noqa: E402  (needs no built library: the digest of the sources in the tree)
 
 
 def small():
@@ -64,7 +65,8 @@ def infer(args):
         print(json.dumps({"metric": "REHEARSAL candidate-variants/sec (CPU oracle double, %d reads)" % cfg.reads, "value": round(len(batch) * args.steps / dt, 2),
                           "unit": "candidate-variants/s", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": 0,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "rehearsal", "config": {"workload": "CPU rehearsal: %d sites per rank" % per_rank}}), flush=True)
+                          "dtype": "f32", "data": "rehearsal", "build": {"source_hash": tree_source_hash()},
+                          "config": {"workload": "CPU rehearsal: %d sites per rank" % per_rank}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -101,7 +103,7 @@ def train(args):
         print(json.dumps({"metric": "REHEARSAL training sites/sec (no device step: gradient exchange over gloo)", "value": round(10 * world * args.steps / dt, 2),
                           "unit": "sites/s", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": 0, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "rehearsal",
-                          "config": {"workload": "CPU rehearsal"},
+                          "config": {"workload": "CPU rehearsal"}, "build": {"source_hash": tree_source_hash()},
                           "exchange": None if world == 1 else {"form": "all-reduce", "backend": "gloo", "bucket_floats": [n0, n1],
                                                                 "exposed_ms_per_step": round(t_ex / args.steps * 1e3, 3), "normalisers_ms_per_step": 0.0}}), flush=True)
     if dist is not None:

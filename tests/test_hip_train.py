@@ -145,6 +145,43 @@ def decisions_differing(tr, w64, cfg, B):
     return out
 
 
+def device_decisions(tr, cfg, B, c_last):
+    """The discrete decisions of the HIP step just run on ``tr`` in the form oracle.dan_train_oracle.train_forward(forced=...) takes:
+    the conv / bottleneck ReLU masks (activation > 0) and the read that won the final max."""
+    R, L = cfg.reads, cfg.length
+    forced = {}
+
+    def rows(name, width, C):
+        return np.transpose(tr.debug_buffer(name, B * R * L * width).reshape(B, R, L, width)[..., :C], (0, 3, 1, 2))
+
+    for l in range(1, cfg.layers + 1):
+        forced["relu%d" % l] = rows("act:a%d" % l, 128, cfg.layer_dims(l)[1]) > 0
+        if cfg.bottleneck > 0:
+            forced["hrelu%d" % l] = rows("act:h%d" % l, 32, cfg.bottleneck) > 0
+    forced["argmax"] = rows("act:x%d" % cfg.layers, 128, c_last).argmax(axis=2)
+    return forced
+
+
+def check_against_the_oracle_with_the_devices_decisions(tr, out, sd, cfg, planes, tg, ohp, masks, B, tag):
+    """The EDGE branch (no 5e-2 bar, no hand-picked seeds as the only strict coverage).  A step one or more of whose ReLU /
+    max decisions went the other way than the float64 oracle's -- on operands within a rounding error of their edge, asserted by the
+    caller -- differentiated a network one rounding error away.  So the oracle is evaluated again, in float64, WITH THE DEVICE'S
+    DECISIONS IMPOSED (train_forward(forced=...)): that is the exact gradient of the network the device differentiated, and the
+    step is held to it at the tight bar -- 1e-4 of each tensor's max plus twice the distance of the fp32 oracle under the same
+    decisions (pure fp32 summation noise: the two share every decision) -- and the clip norm to 2e-4.  A real error in any
+    gradient tensor, the layer-1 / embedding ones included, cannot hide behind a flipped decision any more."""
+    import torch
+    forced = device_decisions(tr, cfg, B, cfg.layer_dims(cfg.layers)[1])
+    want_f = T.train_step_oracle(sd, cfg, planes, tg, ohp, dropout_masks=masks, dtype=torch.float64, forced=forced)
+    w32_f = T.train_step_oracle(sd, cfg, planes, tg, ohp, dropout_masks=masks, forced=forced)
+    grads = {k[5:]: v for k, v in want_f.items() if k.startswith("grad:")}
+    slack = {k: float(np.abs(w32_f["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
+    for k in ("loss", "bin", "vt"):
+        assert abs(out[k] - float(want_f[k])) <= 5e-5 * max(1.0, abs(float(want_f[k]))), (tag, k, out[k], float(want_f[k]))
+    assert abs(out["grad_norm"] - float(want_f["grad_norm"])) <= 2e-4 * max(float(want_f["grad_norm"]), 1e-6), (tag, out["grad_norm"], float(want_f["grad_norm"]))
+    return check_grads(tr, grads, tag + " (float64 oracle under the device's decisions)", slack), max(slack.values())
+
+
 # (sites, reads, synthetic-pileup seed).  (5, 12, 18) is the case rounds 2-4 committed: on the round-5 kernels it takes the EDGE
 # branch (one bottleneck and one conv ReLU input within 5e-6 of zero go the other way), as do seeds 19-21 at that size (~11 M ReLU
 # decisions per step: a few always sit on an edge).  The smaller batches were chosen from tests/diagnostics/prod_width_branch_scan.py
@@ -164,8 +201,9 @@ def test_production_width_step_against_oracle(sites, reads, data_seed):
       * every decision of the HIP step that differs from the float64 oracle's must sit on a rounding edge (operand within
         DECISION_MARGIN of it) -- a decision that differs on a large value is a bug;
       * if NO decision differs, every tensor is within 1e-4 of its max plus twice the fp32 oracle's own distance from float64
-        (the "tight" branch); otherwise (the step computed the gradient of a network one rounding error away) within a loose
-        5e-2 (the "edge" branch).
+        (the "tight" branch); otherwise (the step computed the gradient of a network one rounding error away) the float64 oracle
+        is evaluated again UNDER THE DEVICE'S DECISIONS and the step is held to that at the same tight bar (the "edge" branch;
+        round 6 -- it was a loose 5e-2 against the unforced oracle before).
     WHICH branch a seed took, the decisions that differed with their operands and the worst gradient are written to
     gpurun_out/train_prod_width.json (-> profiles/rNN_train_prod_width.json), so that a green run says what it proved; the
     seeds are chosen so that BOTH branches are exercised on the committed kernels (test_production_width_branches_on_record).
@@ -184,18 +222,20 @@ def _prod_width_report_path():
     return os.path.join(d, "train_prod_width.json")
 
 
+_PROD_WIDTH_SESSION = {}       # report name -> record, of THIS pytest session only (the JSON file is rewritten from it, never merged
+                               # with what an earlier session or build left in gpurun_out/: ADVICE r5)
+
+
 def test_production_width_branches_on_record():
-    """Runs after the seeds above (file order): at least one seed took the tight branch (no decision differs: plain 1e-4 + the fp32
-    oracle's own distance) -- a run in which every seed fell into the loose branch would have proved little."""
-    import json
-    import os
-    path = _prod_width_report_path()
-    if not os.path.isfile(path):
-        pytest.skip("no report: the production-width cases did not run in this session")
-    rep = json.load(open(path))
-    branches = {k: v["branch"] for k, v in rep.items() if k.startswith("sites_")}
+    """Both branches occurred among the production-width cases that ran in THIS session (collected in _PROD_WIDTH_SESSION by the
+    cases themselves, so neither file order, nor -k, nor a stale gpurun_out/train_prod_width.json of an earlier build can satisfy
+    it): some seed with no differing decision (held to the float64 oracle as it is) and some seed with decisions on rounding edges
+    (held to the float64 oracle under the device's decisions)."""
+    branches = {k: v["branch"] for k, v in _PROD_WIDTH_SESSION.items() if k.startswith("sites_")}
+    if len(branches) < len(PROD_WIDTH_CASES):
+        pytest.skip("only %d of the %d production-width cases ran in this session" % (len(branches), len(PROD_WIDTH_CASES)))
     print("production-width branches:", branches)
-    assert "tight" in branches.values(), branches
+    assert "tight" in branches.values() and "edge" in branches.values(), branches
 
 
 def _full_width_step_check(cfg, B, tag, fixed=None, data_seed=18, report=None):
@@ -233,11 +273,8 @@ def _full_width_step_check(cfg, B, tag, fixed=None, data_seed=18, report=None):
     def write():
         if report:
             import json
-            import os
-            path = _prod_width_report_path()
-            allr = json.load(open(path)) if os.path.isfile(path) else {}
-            allr[report] = rec
-            json.dump(allr, open(path, "w"), indent=1)
+            _PROD_WIDTH_SESSION[report] = rec
+            json.dump(_PROD_WIDTH_SESSION, open(_prod_width_report_path(), "w"), indent=1)
     write()                                                      # (also when an assertion below fails: the record says why)
     for kind, l, n, largest in differing:
         assert largest <= DECISION_MARGIN[kind], "%s: %d %s decisions of layer %d differ from the float64 oracle's, one on an operand of %.3g" % (tag, n, kind, l, largest)
@@ -246,9 +283,11 @@ def _full_width_step_check(cfg, B, tag, fixed=None, data_seed=18, report=None):
         rec["bar"] = "1e-4 of the tensor's max + 2 x the fp32 oracle's own distance from float64"
         worst = check_grads(tr, grads, tag, oracle32)
     else:
-        rec["bar"] = "5e-2 of the tensor's max (the step differentiated a network one rounding error away)"
-        worst = check_grads(tr, grads, "%s, %d decisions on rounding edges" % (tag, sum(d[2] for d in differing)),
-                            {k: 0.5 * (5e-2 - GRAD_RTOL) for k in grads})
+        rec["bar"] = ("1e-4 of the tensor's max + 2 x the fp32 oracle's distance, against the float64 oracle evaluated under the "
+                      "device's own ReLU / max decisions (the network the step differentiated)")
+        worst, noise = check_against_the_oracle_with_the_devices_decisions(
+            tr, out, sd, cfg, batch.arrays(), tg, ohp, masks, B, "%s, %d decisions on rounding edges" % (tag, sum(d[2] for d in differing)))
+        rec["fp32_oracle_worst_distance_under_the_devices_decisions"] = noise
     rec["worst_gradient"] = {"tensor": worst[0], "error_over_max": worst[1], "fp32_oracle_error_over_max_same_tensor": oracle32.get(worst[0])}
     write()
     print("%s: %s; worst gradient %s at %.2g of its max" % (
@@ -569,7 +608,8 @@ def run_random_train_case(seed, **shape):
     (tests/diagnostics/train_short_window_sweep.py, train_flip_check.py) showed that the sporadic misses of such cases -- at ANY
     window length, 2e-2 of a tensor's max on a 16-channel network -- are ReLU inputs within 3e-6 of zero that the fp32 step
     decides the other way (the fp32 torch oracle has its own, elsewhere): every differing decision must sit on a rounding
-    edge, and only a step without any is held to the tight bar."""
+    edge; a step without any is held to the float64 oracle at the tight bar, one with some to the float64 oracle evaluated under
+    the device's own decisions at the same bar (check_against_the_oracle_with_the_devices_decisions)."""
     import torch
     kw, cfg, sd, batch, hp, tg, masks = random_train_case(seed, **shape)
     B = len(batch)
@@ -590,8 +630,8 @@ def run_random_train_case(seed, **shape):
         slack = {k: float(np.abs(w32["grad:" + k] - g).max()) / max(float(np.abs(g).max()), 1e-30) for k, g in grads.items()}
         worst = check_grads(tr, grads, tag, slack)
     else:
-        worst = check_grads(tr, grads, "%s, %d decisions on rounding edges" % (tag, sum(d[2] for d in differing)),
-                            {k: 0.5 * (5e-2 - GRAD_RTOL) for k in grads})
+        worst, _ = check_against_the_oracle_with_the_devices_decisions(
+            tr, out, sd, cfg, batch.arrays(), tg, ohp, masks, B, "%s, %d decisions on rounding edges" % (tag, sum(d[2] for d in differing)))
     print("%s: %s; worst gradient %s at %.2g of its max" % (tag, "tight branch" if not differing else "edge branch %s" % (differing,), *worst))
     tr.close()
     return worst, ("tight" if not differing else "edge")

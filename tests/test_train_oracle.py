@@ -66,3 +66,33 @@ def test_dropout_masks_matter_and_bn_uses_batch_statistics():
     tg = {k: v[:3] for k, v in st["targets"].items()}
     sub = train_step_oracle(w, spec, half, tg, hp, dropout_masks=[m[:3] for m in st["masks"]])
     assert np.abs(sub["out:vt_logits"] - base["out:vt_logits"][:3]).max() > 1e-6      # batch statistics couple the sites
+
+
+def test_forced_decisions_mode_reproduces_the_step_it_took_them_from_and_follows_a_flipped_one():
+    """oracle.dan_train_oracle.train_forward(forced=...) -- the GPU tests' edge branch imposes the device's ReLU / max decisions on
+    the float64 oracle.  With the oracle's OWN decisions imposed every output and gradient is reproduced (x * mask == relu(x)
+    wherever the mask is the sign test); with one conv-ReLU decision flipped on an operand near zero, the result is the gradient of
+    that neighbouring network: it differs, and is reproduced by flipping the same decision again."""
+    import torch
+    spec, hyper, w, steps, *_ = load_train_case("train_small")
+    hp, st = TrainHyper(**hyper), steps[0]
+    base = train_step_oracle(w, spec, st["planes"], st["targets"], hp, dropout_masks=st["masks"], dtype=torch.float64, taps=True)
+    forced = {}
+    for l in range(1, spec["layers"] + 1):
+        forced["relu%d" % l] = base["tap:pre%d" % l] > 0
+        forced["hrelu%d" % l] = base["tap:hpre%d" % l] > 0
+    forced["argmax"] = base["tap:conv%d" % spec["layers"]].argmax(axis=2)
+    same = train_step_oracle(w, spec, st["planes"], st["targets"], hp, dropout_masks=st["masks"], dtype=torch.float64, forced=forced)
+    for k, v in base.items():
+        if k.startswith(("grad:", "out:")) or k in ("loss", "grad_norm"):
+            assert np.abs(same[k] - v).max() <= 1e-12 * max(1.0, float(np.abs(v).max())), k
+    pre = base["tap:pre3"]
+    i = np.unravel_index(np.abs(pre).argmin(), pre.shape)              # the decision closest to its edge
+    flipped = dict(forced)
+    flipped["relu3"] = forced["relu3"].copy()
+    flipped["relu3"][i] = ~flipped["relu3"][i]
+    other = train_step_oracle(w, spec, st["planes"], st["targets"], hp, dropout_masks=st["masks"], dtype=torch.float64, forced=flipped)
+    moved = max(float(np.abs(other[k] - base[k]).max()) / max(float(np.abs(base[k]).max()), 1e-30) for k in base if k.startswith("grad:"))
+    assert moved > 1e-9, "flipping a decision changed nothing"
+    again = train_step_oracle(w, spec, st["planes"], st["targets"], hp, dropout_masks=st["masks"], dtype=torch.float64, forced=flipped)
+    assert all(np.array_equal(again[k], other[k]) for k in other if k.startswith("grad:"))

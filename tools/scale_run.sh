@@ -15,7 +15,7 @@
 # proves the launch paths and the table, not a rate.
 set -eo pipefail
 cd "$(dirname "$0")/.."
-gpus=""; sites=1048576; out=gpurun_out/scale; steps=5; rehearse=0
+gpus=""; sites=1048576; out=gpurun_out/scale; steps=5; rehearse=0; failed=0
 while [ $# -gt 0 ]; do
     case "$1" in
         --gpus) gpus=$2; shift 2;;
@@ -47,26 +47,39 @@ for n in $ns; do
     for mode in infer train; do
         f="$out/${mode}_n$n.json"
         echo "--- $mode, $n rank(s)" | tee -a "$out/scale_run.log"
+        ok=1
         if [ "$rehearse" -gt 0 ]; then
             port=$((port + 1))
             python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
-                tests/rehearse_scale_rank.py --mode "$mode" --gpus "$n" --steps 2 > "$f" 2> "$out/${mode}_n$n.err"
+                tests/rehearse_scale_rank.py --mode "$mode" --gpus "$n" --steps 2 > "$f" 2> "$out/${mode}_n$n.err" || ok=0
         elif [ "$mode" = infer ]; then
-            python bench.py --gpus "$n" --steps "$steps" --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path > "$f" 2> "$out/${mode}_n$n.err"
+            python bench.py --gpus "$n" --steps "$steps" --warmup 1 --no-cpu-baseline --no-skip-pass --no-host-path > "$f" 2> "$out/${mode}_n$n.err" || ok=0
         else
-            python bench.py --mode train --gpus "$n" --steps $((steps * 4)) --warmup 3 --no-cpu-baseline > "$f" 2> "$out/${mode}_n$n.err"
+            python bench.py --mode train --gpus "$n" --steps $((steps * 4)) --warmup 3 --no-cpu-baseline > "$f" 2> "$out/${mode}_n$n.err" || ok=0
         fi
-        tail -n 1 "$f" | cut -c1-200 | tee -a "$out/scale_run.log"
+        # a run that fails must not take the table with it (set -e): its row reads FAILED there, the script exits non-zero at the end
+        if [ "$ok" = 0 ]; then
+            failed=$((failed + 1)); : > "$f"
+            echo "run failed: see $out/${mode}_n$n.err" | tee -a "$out/scale_run.log"
+        else
+            tail -n 1 "$f" | cut -c1-200 | tee -a "$out/scale_run.log"
+        fi
     done
 done
 # ---- the CLI path: main.py --gpus N on a generated candidates.hdf
 echo "--- main.py --gpus $N on $sites generated sites" | tee -a "$out/scale_run.log"
+ok=1
 if [ "$rehearse" -gt 0 ]; then
-    python tests/rehearse_scale_rank.py --mode cli --gpus "$N" --out "$out" > "$out/main_n$N.txt" 2> "$out/main_n$N.err"
+    python tests/rehearse_scale_rank.py --mode cli --gpus "$N" --out "$out" > "$out/main_n$N.txt" 2> "$out/main_n$N.err" || ok=0
 else
-    python tools/scale_table.py --make-inputs "$out" --sites "$sites"
+    python tools/scale_table.py --make-inputs "$out" --sites "$sites" &&
     python main.py --test_file "$out/candidates.hdf" --modelload "$out/ckpt.pth.tar" --sample_vcf "$out/candidates.vcf" --save_vcf_records \
         --save_vcf_records_file "$out/model_test.vcf" --gpus "$N" --sites-per-launch 4096 $(python tools/scale_table.py --model-flags) \
-        > "$out/main_n$N.txt" 2> "$out/main_n$N.err"
+        > "$out/main_n$N.txt" 2> "$out/main_n$N.err" || ok=0
+fi
+if [ "$ok" = 0 ]; then
+    failed=$((failed + 1)); rm -f "$out/main_n$N.txt"
+    echo "run failed: see $out/main_n$N.err" | tee -a "$out/scale_run.log"
 fi
 python tools/scale_table.py --table "$out" --gpus "$N" | tee -a "$out/scale_run.log"
+if [ "$failed" -gt 0 ]; then echo "$failed run(s) FAILED" | tee -a "$out/scale_run.log"; exit 1; fi

@@ -53,25 +53,37 @@ def last_line(path):
 def table(out, gpus):
     rows = []
     base = {}
+    base_lib = {}
+    mixed = []
     for mode in ("infer", "train"):
         for f in sorted(glob.glob(os.path.join(out, "%s_n*.json" % mode)), key=lambda p: int(re.search(r"_n(\d+)\.json", p).group(1))):
             n = int(re.search(r"_n(\d+)\.json", f).group(1))
             rec = last_line(f)
             if rec is None:
-                rows.append((mode, n, "FAILED (see %s)" % f.replace(".json", ".err"), "", "", "", ""))
+                rows.append((mode, n, "FAILED (see %s)" % f.replace(".json", ".err"), "", "", "", "", ""))
                 continue
+            # which library wrote the line (bench.py's `build.source_hash` = dan_source_hash() of the loaded libdl4vc_dan.so): printed
+            # beside every row, and a row whose library is not the n = 1 row's says so -- a table can never silently mix builds
+            lib = str((rec.get("build") or {}).get("source_hash", "?"))
             if n == 1:
                 base[mode] = rec["value"]
+                base_lib.setdefault("hash", lib)
             eff = "%.3f" % (rec["value"] / (n * base[mode])) if mode in base else "-"
+            if "hash" in base_lib and lib != base_lib["hash"]:
+                lib += " MIXED"
+                mixed.append((mode, n))
             ex = rec.get("exchange") or {}
             rows.append((mode, n, "%.0f %s" % (rec["value"], rec["unit"]), "%.2f" % rec["ms_per_step"], eff,
-                         "%d" % rec.get("ranks_seen", -1),
+                         "%d" % rec.get("ranks_seen", -1), lib,
                          ("%.2f ms exposed + %.2f ms normalisers, %s" % (ex["exposed_ms_per_step"], ex["normalisers_ms_per_step"], ex["form"])) if ex else
                          ("no exchange (one rank)" if mode == "train" else "no collective on the data path")))
     print()
-    print("%-6s %3s  %-34s %12s %10s %10s  %s" % ("mode", "n", "whole-job rate", "ms per step", "efficiency", "ranks_seen", "gradient exchange"))
+    print("%-6s %3s  %-34s %12s %10s %10s  %-22s %s" % ("mode", "n", "whole-job rate", "ms per step", "efficiency", "ranks_seen", "library (source hash)", "gradient exchange"))
     for r in rows:
-        print("%-6s %3d  %-34s %12s %10s %10s  %s" % r)
+        print("%-6s %3d  %-34s %12s %10s %10s  %-22s %s" % r)
+    if mixed:
+        print("WARNING: rows %s were written by another build of libdl4vc_dan.so than the n = 1 row (%s): efficiencies across them mean nothing"
+              % (", ".join("%s n=%d" % m for m in mixed), base_lib["hash"]))
     log = os.path.join(out, "main_n%d.txt" % gpus)
     print()
     if os.path.isfile(log):
