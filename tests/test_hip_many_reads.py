@@ -123,9 +123,14 @@ def test_plain_bf16_at_128_reads_against_the_references_bf16_run(bf16_form):
     got = net.forward_u8(*planes, aux=True)
     net.close()
     # (1) conv2 of site 0 against the reference's own bf16 run
+    # (the kernel's y1 is its own fp32 sum rounded to bf16: where that sum lands on a rounding edge the stored value is one bf16 ulp
+    # from the reference's operand, and that moves the 3-tap outputs it feeds by up to |W2| ulp(y1) -- `upstream`, allowed for at most
+    # 1e-4 of the elements: first run on the box 3 of 616 448 elements, 99.9925 % bit-identical)
     ref2 = bf16_round(torch.from_numpy(out["conv2"])).numpy()
     g2 = taps[2].transpose(0, 3, 1, 2)[:1, :C]
-    _compare(g2, ref2, "conv2 vs the reference's bf16 run")
+    y1_max = float(np.abs(taps[1]).max())
+    up2 = 2.0 * float(np.abs(w["conv1D_layers.1.weight"]).max()) * float(_ulp_bf16(np.array([y1_max]))[0])
+    _compare(g2, ref2, "conv2 vs the reference's bf16 run", upstream=up2)
     assert not taps[2][..., C:].any(), "pad channels must stay zero"
     # (2) the read-mean over 128 rows of the kernel's own image
     want_pool = taps[2].astype(np.float64).mean(axis=1)
