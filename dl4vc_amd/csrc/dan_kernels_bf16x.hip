@@ -160,6 +160,15 @@ __device__ __forceinline__ void gemm_x(v4f (&acc)[2][PT], const char* lds, unsig
         }
         if (s + NA < S) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
     }
+    // Eight wait states between the walk's last MFMA and whatever reads an accumulator next (the caller's epilogue).  gfx950 has no
+    // interlock for a VALU read of a register an MFMA is still writing; hipcc covers it with s_nop -- but not on every path: the last
+    // step's `skip_last` branch jumps from the MFMAs of tile PT - 2 straight to the join, and ROCm 7.2's hazard recognizer, which walks
+    // a block's predecessors with one visited-set for all paths, can miss that edge (it reaches the branch block first THROUGH the
+    // skipped block).  With hipcc's default and max-ilp schedules the tiles read first behind the join are finished long before it, so
+    // nothing is wrong today; under -amdgpu-sched-strategy=iterative-ilp their last MFMA is the instruction in front of the branch and
+    // the second-half waves read a stale accumulator now and then (one 16-column tile of one row in ~16 k: HISTORY.md section 14.2,
+    // tools/isa_hazard_check.py, tests/test_isa_hazards.py).  The nop makes the join safe whatever the schedule: 8 of ~18 k cycles.
+    asm volatile("s_nop 7");
 }
 
 __device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
