@@ -413,8 +413,12 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
         cst_put(a.l_begin);
         if (resumed) {
             // this wave's pieces of the DMA'd image have landed.  Behind them in the queue are only the previous row's copy-out stores
-            // (at least L / 16 per wave): they may stay in flight
-            if (!SPLIT && L >= 192) __builtin_amdgcn_s_waitcnt(0x0F70 | 12);   // vmcnt(12)
+            // (at least L / 16 per wave): they may stay in flight.  vmcnt(12) proves the DMA done only if at least TWELVE operations
+            // were issued behind it -- true of the copy-out (L >= 192: six full sweeps per plane for every lane), not of a workgroup's
+            // FIRST row, whose DMA is followed by the seed loads alone: a second-half wave issues 2 per tile with a column inside the
+            // window, ten at L = 192 exactly (found by reading the count's assumptions in round 6; the first row needs its seed at
+            // once anyway, so waiting for everything there costs nothing)
+            if (!SPLIT && L >= 192 && k != jw) __builtin_amdgcn_s_waitcnt(0x0F70 | 12);   // vmcnt(12)
             else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)  (a split unit stores fewer than twelve chunks per thread)
         }
         __syncthreads();

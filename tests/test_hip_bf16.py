@@ -135,10 +135,12 @@ def test_bf16x3_production_shape(reads):
     net.close(); b.close(); c.close()
 
 
-@pytest.mark.parametrize("length", [120, 176, 208])
+@pytest.mark.parametrize("length", [120, 176, 192, 193, 208])
 def test_bf16x3_other_window_lengths(length):
     """Windows that end inside the second half's first tile, on a tile edge and at the capacity of the image (the fourteenth tile is a
-    phantom: columns 208..223 are never part of a window)."""
+    phantom: columns 208..223 are never part of a window) -- and 192 / 193 columns, either side of the length at which the resumed
+    segment stops waiting for everything and counts the operations behind its LDS-DMA instead (vmcnt(12): at 192 the second half's
+    sixth tile has no column inside the window and a workgroup's first row has only ten seed loads behind its DMA)."""
     cfg = DanConfig(reads=12, length=length, c_init=64, c_final=48, fc_sizes=(96, 32), precision=PRECISION_BF16X3)
     sd = random_state_dict(cfg, seed=11)
     batch = synth.make_sites(3, reads=12, length=length, seed=12)
