@@ -86,11 +86,12 @@ __device__ __forceinline__ void conv_gemm(v4f (&acc)[MTW][NT], const float* xs, 
 // NW = participating waves: all 8 (standalone stage), or only the 4 OLDER waves (0..3, one per SIMD) when the GEMM is
 // deferred into the next layer's conv stage (see the Winograd layer body).
 // RANGE: only positions p_lo <= p < L are stored (a unit of a split read stores its own columns; dan_kernels.hip SPLIT).
-template <int NW, bool RANGE = false>
+// TILES: 16-column tiles the image holds for this instantiation (MT; 12 for the split kernel's short units, dan_kernels.hip TW = 6).
+template <int NW, bool RANGE = false, int TILES = MT>
 __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC], const float* bbot, float* hrow, int L,
                                            int wave, int lane, int p_lo = 0) {
     constexpr int PSTEP = NW / 2;                         // position-tile stride of one wave
-    constexpr int NBT = (MT + PSTEP - 1) / PSTEP;
+    constexpr int NBT = (TILES + PSTEP - 1) / PSTEP;
     // everything below is recomputed per call from an opaque copy of the lane index: hoisted out of the layer loop, the
     // per-tile offsets and 64-bit store addresses would sit in registers through the conv GEMMs (and spill)
     lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // (not even the lane index is kept)
@@ -100,7 +101,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
     const float* xrow = xs + (HALO + pos) * LDS_S + kk * 4;
     int roff[NBT];
 #pragma unroll
-    for (int i = 0; i < NBT; ++i) roff[i] = min(p0 + PSTEP * i, MT - 1) * 16 * LDS_S;
+    for (int i = 0; i < NBT; ++i) roff[i] = min(p0 + PSTEP * i, TILES - 1) * 16 * LDS_S;
     v4f acc[NBT], b[NBT];
     {
         const v4f bias = *(const v4f*)(bbot + n * 16 + kk * 4);
@@ -127,7 +128,7 @@ __device__ __forceinline__ void bottleneck(const float* xs, const v4f (&wf)[KGC]
 #pragma unroll
     for (int i = 0; i < NBT; ++i) {
         const int pt = p0 + PSTEP * i, p = pt * 16 + pos;
-        if (pt < MT && p < L && (!RANGE || p >= p_lo)) {
+        if (pt < TILES && p < L && (!RANGE || p >= p_lo)) {
             v4f v = acc[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = relu1(v[j]);
@@ -149,10 +150,19 @@ __device__ __forceinline__ void copy_out(const float* xs, float* dst, int lo, in
 // ------------------------------------------------------------------------------------------------
 constexpr int MW = 7;                   // Winograd tiles per lane
 constexpr int WHB = 102;                // first position of the upper half's tiling
+// The split kernel's short units (windows of 209..304 columns, two units of <= 190 columns each: 161 at 301 columns) take SIX tiles per
+// lane: the lower-half lanes tile [0, 96), the upper-half lanes [94, 190) -- 94 == 2 mod 4 like 102, so that the sixteen lanes of a
+// ds_read_b128 group still touch rows of all eight residues mod 8.  6 / 7 of the matrix work of a layer for such a unit.
+constexpr int MW_SHORT = 6;
+constexpr int WHB_SHORT = 94;
+constexpr int MPOS_SHORT = WHB_SHORT + 16 * MW_SHORT;    // 190: the longest unit the six-tile form covers
+constexpr int wino_half_base(int tw) { return tw == MW ? WHB : WHB_SHORT; }
+constexpr int wino_cover(int tw) { return tw == MW ? MPOS : MPOS_SHORT; }
+template <int TW = MW>
 __device__ __forceinline__ int wino_base(int lane) {
     const int n = lane & 15;
     const int c = n & 1, hf = (n >> 2) & 1, q = ((n >> 1) & 1) + 2 * (((n >> 3) ^ (n >> 2)) & 1);
-    return hf * WHB + 4 * q * MW + c;
+    return hf * wino_half_base(TW) + 4 * q * TW + c;
 }
 
 // acc[m][k] += U_k[own 16 channels][all 128 in-channels] * V_k[tile m]
@@ -168,7 +178,8 @@ __device__ __forceinline__ v4f pk_sub(v4f a, v4f b, v2f m1) {
     return (v4f){lo[0], lo[1], hi[0], hi[1]};
 }
 __device__ __forceinline__ v4f pk_add(v4f a, v4f b) { return a + b; }
-__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
+template <int TW>
+__device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[TW][4], const float* xrow, gv4f_ptr wl, const v4f (&a_first)[4]) {
     v4f a_nxt[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) a_nxt[k] = a_first[k];
@@ -187,10 +198,10 @@ __device__ __forceinline__ void conv_gemm_wino(v4f (&acc)[MW][4], const float* x
         const float* xg = xrow + g * 16;
         const float* xn = xrow + gn * 16;
 #pragma unroll
-        for (int m = 0; m < MW; ++m) {
+        for (int m = 0; m < TW; ++m) {
             v4f v[4];
             v[0] = pk_sub(xa, xc, m1); v[1] = pk_add(xb, xc); v[2] = pk_sub(xc, xb, m1); v[3] = pk_sub(xb, xd, m1);
-            if (m + 1 < MW) {
+            if (m + 1 < TW) {
                 xa = xc; xb = xd;
                 xc = *(const v4f*)(xg + (4 * m + 8) * LDS_S);
                 xd = *(const v4f*)(xg + (4 * m + 10) * LDS_S);

@@ -50,12 +50,16 @@ constexpr int NSTAMP = 64;
 // may run past the activation into the constants that follow it in LDS) produce columns nobody stores.
 static_assert((HALO + WHB + 4 * (4 * MW - 1) + 1 + 4 + 1) * LDS_S <= LDS_ROWS * LDS_S + MAX_LAYERS * CST_FLOATS, "wino reads stay inside LDS");
 static_assert(WHB + 4 * (4 * MW - 1) + 3 >= MPOS - 1 && 4 * (4 * MW - 1) + 3 >= WHB - 1, "wino tiling covers the read");
+// ... and the six-tile form of the split kernel's short units (dan_device.h MW_SHORT): [0, 96) + [94, 190)
+static_assert(WHB_SHORT + 4 * (4 * MW_SHORT - 1) + 3 >= MPOS_SHORT - 1 && 4 * (4 * MW_SHORT - 1) + 3 >= WHB_SHORT - 1 && WHB_SHORT % 4 == 2,
+              "short wino tiling covers its unit");
 
 // 1x1 GEMM in the same column mapping: acc[m][o] += W[own 16 channels][128] * x(P(m) + 2 o)
-__device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xrow, gv4f_ptr wl, v4f a_first) {
-    v4f a_nxt = a_first, b[MW][2];
+template <int TW>
+__device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[TW][2], const float* xrow, gv4f_ptr wl, v4f a_first) {
+    v4f a_nxt = a_first, b[TW][2];
 #pragma unroll
-    for (int m = 0; m < MW; ++m)
+    for (int m = 0; m < TW; ++m)
 #pragma unroll
         for (int o = 0; o < 2; ++o) b[m][o] = *(const v4f*)(xrow + (4 * m + 2 * o) * LDS_S);
     for (int g = 0; g < KGC; ++g) {
@@ -63,7 +67,7 @@ __device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xro
         const int gn = (g + 1 < KGC) ? g + 1 : g;
         a_nxt = wl[(size_t)gn * (KGC * 64)];
 #pragma unroll
-        for (int m = 0; m < MW; ++m) {
+        for (int m = 0; m < TW; ++m) {
             __builtin_amdgcn_s_setprio(3);                      // MFMAs ahead of the other wave's LDS/VALU work, as in conv_gemm_wino
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -88,8 +92,12 @@ __device__ __forceinline__ void gemm1x1_wino(v4f (&acc)[MW][2], const float* xro
 // item is (row, unit), `L` below is the UNIT's length and every position-indexed pointer is offset to the unit's first column;
 // what differs from the one-unit form is addressing (window stride Lw), the allele-agreement predicates (taken over the whole
 // window, not the unit) and the stores (own columns only, y out of place).  SPLIT = false compiles to the code it always was.
-template <bool WINO, bool PERSIST, bool SPLIT>
+// TW: Winograd tiles per lane -- MW = 7 (one unit of up to 208 columns) or, SPLIT, MW_SHORT = 6 (units of up to 190 columns: every
+// unit of a split Winograd read, e.g. 161 columns at a 301-column window; launch_segment).
+template <bool WINO, bool PERSIST, bool SPLIT, int TW = MW>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segment_kernel(SegmentArgs a_by_value) {
+    static_assert((!(SPLIT && WINO) && TW == MW) || (SPLIT && WINO && TW == MW_SHORT), "six tiles per lane: the split Winograd kernel, and only it");
+    constexpr int TILES = TW == MW ? MT : (MPOS_SHORT + 15) / 16;           // 16-column tiles of the unit (bottleneck, table walk)
     // one allocation, so that the layout the Winograd tiles past the window rely on (constants right after the activation
     // rows) is explicit
     __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * LDS_S + MAX_LAYERS * CST_FLOATS];
@@ -145,8 +153,8 @@ next_row:                                                   // (PERSIST only: ba
 
     STAMP(0);
     // Winograd column mapping of this lane (used by the WINO instantiation on its dilation-2 layers)
-    [[maybe_unused]] const int wP0 = wino_base(lane);
-    [[maybe_unused]] const int wlim = ((lane >> 2) & 1) ? MPOS : WHB;      // positions this lane's tiling owns: p < wlim
+    [[maybe_unused]] const int wP0 = wino_base<TW>(lane);
+    [[maybe_unused]] const int wlim = ((lane >> 2) & 1) ? wino_cover(TW) : wino_half_base(TW);      // positions this lane's tiling owns: p < wlim
     [[maybe_unused]] const int chw = wave * 16 + kk * 4;
     auto dil_of = [&](int l) { return (l == 0) ? 1 : (l + 1 < a.n_layers ? a.dil_mid : a.dil_final); };
     auto wino_layer = [&](int l) { return WINO && l > 0; };
@@ -249,7 +257,7 @@ next_row:                                                   // (PERSIST only: ba
         // a single CU streams at (bytes in flight) / latency: put the whole read (and the pool image) in flight
         // at once -- 26 + 26 sixteen-byte loads per lane -- instead of a few loads per round trip
         const int n4 = L * (CPAD / 4);
-        constexpr int NP = MPOS * (CPAD / 4) / SEG_THREADS;
+        constexpr int NP = TILES * 16 * (CPAD / 4) / SEG_THREADS;
         v4f vy[NP], vp[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -302,7 +310,7 @@ next_row:                                                   // (PERSIST only: ba
         // each SIMD is still in its conv GEMM (the arbiter serves the older wave first, so it finishes the conv early and
         // would only wait at the barrier)
         if (a.has_hw && !(WINO && l + 1 < a.l_end))
-            bottleneck<NWAVE, SPLIT>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + (read_idx * (size_t)Lw + u_off) * HPAD,
+            bottleneck<NWAVE, SPLIT, TILES>(xs, wbot, lc + CST_BBOT, a.h + (size_t)l * a.h_layer_stride + (read_idx * (size_t)Lw + u_off) * HPAD,
                                      own_hi, wave, lane, own_lo);
         STAMP(sb + 7);
         if (CARRY) { pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3; }
@@ -448,14 +456,14 @@ next_row:                                                   // (PERSIST only: ba
         gv4f_ptr w_w = (gv4f_ptr)(wblk + WW_OFF) + wave * 64 + lane;
         gv4f_ptr w_r1 = (gv4f_ptr)(wblk + WRES_OFF) + wave * 64 + lane;
         float* xw = xs + (HALO + wP0) * LDS_S;          // row of x(P(0)) (channel 0)
-        v4f out[MW][2], pre_r1;
+        v4f out[TW][2], pre_r1;
         int wp = wP0;
         float* xq;
         {
-            v4f acc[MW][4];
+            v4f acc[TW][4];
             const v4f bias = *(const v4f*)(lc + CST_BIAS + chw);
 #pragma unroll
-            for (int m = 0; m < MW; ++m) { acc[m][0] = splat(0.f); acc[m][1] = bias; acc[m][2] = splat(0.f); acc[m][3] = splat(0.f); }
+            for (int m = 0; m < TW; ++m) { acc[m][0] = splat(0.f); acc[m][1] = bias; acc[m][2] = splat(0.f); acc[m][3] = splat(0.f); }
             STAMP(sb + 0);
             if constexpr (CARRY) {
                 const v4f pre_w[4] = {pc0, pc1, pc2, pc3};
@@ -481,7 +489,7 @@ next_row:                                                   // (PERSIST only: ba
                 return __builtin_elementwise_fma(r, s, t);
             };
 #pragma unroll
-            for (int m = 0; m < MW; ++m) {
+            for (int m = 0; m < TW; ++m) {
                 const v2f y0l = half(acc[m][0], 0) + half(acc[m][1], 0) + half(acc[m][2], 0), y0h = half(acc[m][0], 1) + half(acc[m][1], 1) + half(acc[m][2], 1);
                 // (a - b as fma(b, -1, a): exact, and a packed instruction -- hipcc splits a subtraction of pairs into two scalar ones)
                 const v2f y1l = __builtin_elementwise_fma(half(acc[m][3], 0), neg1, __builtin_elementwise_fma(half(acc[m][2], 0), neg1, half(acc[m][1], 0)));
@@ -503,7 +511,7 @@ next_row:                                                   // (PERSIST only: ba
             gv4f_ptr w_bp = (gv4f_ptr)(wblk - LAYER_STRIDE + WBOT_OFF) + lane;
 #pragma unroll
             for (int g = 0; g < KGC; ++g) wbot[g] = w_bp[(g * 2 + (wave & 1)) * 64];
-            bottleneck<NWAVE / 2, SPLIT>(xs, wbot, lc - CST_FLOATS + CST_BBOT,
+            bottleneck<NWAVE / 2, SPLIT, TILES>(xs, wbot, lc - CST_FLOATS + CST_BBOT,
                                          a.h + (size_t)(l - 1) * a.h_layer_stride + (read_idx * (size_t)Lw + u_off) * HPAD, own_hi, wave, lane, own_lo);
         }
         const bool bot_here = a.has_hw && !(l + 1 < a.l_end);
@@ -520,7 +528,7 @@ next_row:                                                   // (PERSIST only: ba
             // Two loops under one uniform branch (as one loop with the choice inside, every cell carried both paths and their masks).
             if (from_global) {
 #pragma unroll
-                for (int m = 0; m < MW; ++m)
+                for (int m = 0; m < TW; ++m)
 #pragma unroll
                     for (int o = 0; o < 2; ++o) {
                         const int p = wp + 4 * m + 2 * o;
@@ -533,7 +541,7 @@ next_row:                                                   // (PERSIST only: ba
                     }
             } else {
 #pragma unroll
-                for (int m = 0; m < MW; ++m)
+                for (int m = 0; m < TW; ++m)
 #pragma unroll
                     for (int o = 0; o < 2; ++o) {
                         const int p = wp + 4 * m + 2 * o;
@@ -556,7 +564,7 @@ next_row:                                                   // (PERSIST only: ba
             }
             __syncthreads();
 #pragma unroll
-            for (int m = 0; m < MW; ++m)
+            for (int m = 0; m < TW; ++m)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int p = wp + 4 * m + 2 * o;
@@ -564,7 +572,7 @@ next_row:                                                   // (PERSIST only: ba
                 }
         } else {
 #pragma unroll
-            for (int m = 0; m < MW; ++m)
+            for (int m = 0; m < TW; ++m)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int p = wp + 4 * m + 2 * o;
@@ -597,7 +605,7 @@ next_row:                                                   // (PERSIST only: ba
         const v4f* tj = (const v4f*)(a.l0_tab + L0_TJ_OFF) + c4;
         const v4f* pe = (const v4f*)(a.l0_tab + L0_PE_OFF) + (size_t)u_off * (CPAD / 4) + c4;
 #pragma unroll 4
-        for (int k = 0; k < MT; ++k) {
+        for (int k = 0; k < TILES; ++k) {
             const int p = min(pr + 16 * k, L - 1);                   // (clamped: the last sweep's extra threads recompute column L - 1)
             const int var = (p == 0) ? 1 : (p == L - 1) ? 2 : 0;         // which neighbours the unit has at this column
             const v4f pe0 = pe[((size_t)var * Lw + p) * (CPAD / 4)];
@@ -671,11 +679,17 @@ void launch_segment(const SegmentArgs& a0, int n_sites, int max_wgs, hipStream_t
     const bool persist = a.work_count != nullptr && max_wgs >= 8 && max_wgs < a.n_rows * units;
     const dim3 grid((unsigned)(persist ? (max_wgs & ~7) : 8 * a.xcd_rows * units)), blk(SEG_THREADS);
     if (split) {
+        // The Winograd form of a split read always runs six tiles per lane: its layers have dilation 2, so a unit is at most
+        // ceil(304 / 2) + 1 + 2 (MAX_LAYERS - 1) = 183 columns <= MPOS_SHORT.  (A longer unit -- not constructible today -- takes the
+        // direct form, which tiles the whole 208-column image.)
+        static_assert((304 + 1) / 2 + 1 + 2 * (MAX_LAYERS - 1) <= MPOS_SHORT, "a split Winograd unit fits the six-tile form");
+        const bool wino = a.wino && a.L <= MPOS_SHORT;
+        a.wino = wino;
         if (persist) {
-            if (a.wino) hipLaunchKernelGGL((segment_kernel<true, true, true>), grid, blk, 0, s, a);
+            if (wino) hipLaunchKernelGGL((segment_kernel<true, true, true, MW_SHORT>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((segment_kernel<false, true, true>), grid, blk, 0, s, a);
         } else {
-            if (a.wino) hipLaunchKernelGGL((segment_kernel<true, false, true>), grid, blk, 0, s, a);
+            if (wino) hipLaunchKernelGGL((segment_kernel<true, false, true, MW_SHORT>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((segment_kernel<false, false, true>), grid, blk, 0, s, a);
         }
     } else if (persist) {

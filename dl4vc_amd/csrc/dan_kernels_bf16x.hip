@@ -187,10 +187,10 @@ __device__ __forceinline__ void load_first(bf8 (&f)[2][4], gbf8 w) {
 // conv GEMM ~7 k cycles before waves 4-7 and would wait at the barrier: they run the PREVIOUS layer's bottleneck in that wait,
 // from the image the GEMM has just read (as the fp32 kernel does).
 // p_lo, p_hi: the columns that are stored (a unit of a split read stores its own columns only; default: the whole window)
-template <int NW>
+template <int NW, int XPT = X_PT>
 __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const float* bbp, float* hrow, int L, int wave, int lane,
                                              int p_lo = 0, int p_hi = 1 << 30) {
-    constexpr int NT = 2 * X_PT, NTL = (NT + NW - 1) / NW, N = X_KS * NTL;
+    constexpr int NT = 2 * XPT, NTL = (NT + NW - 1) / NW, N = X_KS * NTL;
     asm volatile("" : "+v"(lane));                               // (addresses formed here, not ahead of the layer loop)
     const int n = lane & 15, g = lane >> 4;
     const unsigned xa0 = cell_addr(P_HALO + n, g);
@@ -243,9 +243,11 @@ __device__ __forceinline__ void bottleneck_x(const char* lds, gbf8 wbot, const f
 // unit's first column of a window of Lw columns, the agreement predicates look at the whole window, a unit stores (y, h, tap) its
 // own columns only and y crosses segments out of place.  SPLIT = false is the kernel as it was.
 struct XUnit { int off, lo, hi; };                              // first window column, own columns [lo, hi) (unit-relative)
-template <bool SPLIT>
+// PT: 16-column tiles per wave -- X_PT = 7 (units of up to 208 columns: 7 + 6 tiles per SIMD, the fourteenth is the phantom), or 6 for
+// the split kernel's units of up to 192 columns (6 + 5 tiles per SIMD at the 161 columns of a 301-column window: 11 / 13 of the work).
+template <bool SPLIT, int PT = X_PT>
 __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(SegmentXArgs a) {
-    constexpr int PT = X_PT;
+    static_assert(PT == X_PT || (SPLIT && PT == X_PT - 1), "the six-tile form exists for split units only");
     __shared__ __attribute__((aligned(16))) char lds[X_LDS_BYTES];
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             // (Tried in round 5: all sixteen weight fragments of this stage in ONE round trip -- the older waves' stage fell from 6.6 k to
             // 4.7 k cycles under the stamps, but the 64 registers beside the live accumulators spilled 76 and the bench lost 10 %.)
             if (defer)
-                bottleneck_x<NWAVE / 2>(lds, (gbf8)(blk_of(l - 1) + WX_BOT_OFF) + lane, (const float*)(blk_of(l - 1) + WX_CST_OFF) + CST_BBOT,
+                bottleneck_x<NWAVE / 2, PT>(lds, (gbf8)(blk_of(l - 1) + WX_BOT_OFF) + lane, (const float*)(blk_of(l - 1) + WX_CST_OFF) + CST_BBOT,
                                         a.h + (size_t)(l - 1) * a.h_layer_stride + (read_idx * (size_t)Lw + cu.off) * HPAD, L, wave, lane, cu.lo, cu.hi);
             XFENCE();
             XSTAMP(sb + 7);
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(SEG_THREADS, NWAVE / 4) void segmentx_kernel(Segmen
             XSTAMP(sb + 5);
             if (a.tap && a.tap_layer == l + 1) copy_tap(CPAD);
             if (a.has_hw && last_layer)
-                bottleneck_x<NWAVE>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
+                bottleneck_x<NWAVE, PT>(lds, (gbf8)(blk + WX_BOT_OFF) + lane, (const float*)(blk + WX_CST_OFF) + CST_BBOT,
                                     a.h + (size_t)l * a.h_layer_stride + (read_idx * (size_t)Lw + cu.off) * HPAD, L, wave, lane, cu.lo, cu.hi);
             XSTAMP(sb + 6);
         }
@@ -631,7 +633,8 @@ void launch_segmentx(const SegmentXArgs& a0, int n_sites, int n_cus, hipStream_t
     if (wgs > need) wgs = need;
     // one row takes ~30 us (layers 1-2) / ~100 us (layers 3-7): the offsets spread the workgroups over about one row
     if (a.stagger < 0) a.stagger = (a.l_end - a.l_begin) <= 2 ? 1 : 3;
-    if (split) hipLaunchKernelGGL(x3::segmentx_kernel<true>, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    if (split && a.L <= 2 * (X_PT - 1) * 16) hipLaunchKernelGGL((x3::segmentx_kernel<true, X_PT - 1>), dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
+    else if (split) hipLaunchKernelGGL(x3::segmentx_kernel<true>, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
     else hipLaunchKernelGGL(x3::segmentx_kernel<false>, dim3((unsigned)wgs), dim3(SEG_THREADS), 0, s, a);
 }
 
