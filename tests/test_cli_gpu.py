@@ -335,3 +335,56 @@ print("ok", out["loss"])
 ''' % (ROOT, ROOT))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_acceptance_procedure_end_to_end_on_synthetic_candidates(tmp_path, precision):
+    """INTEGRATION.md section 9, rehearsed: `main.py` scores a candidates.hdf on the GPU (A); the oracle -- standing in for the
+    reference's own run, which it is pinned to -- scores the same sites and its scored VCF is written by the same %.8f splice (B);
+    `tools/compare_calls.py A B --candidates candidates.hdf` must accept: every score within 1e-4, genotype lines of the two identical
+    away from decision thresholds, the two deep pileups (> 100 reads: a random read subset in the reference) set apart."""
+    import json
+    import torch
+    from dl4vc_amd.dataset import assemble_batch
+    from dl4vc_amd.vcf import start_scored_vcf, append_scored_records
+    cfg = DanConfig()
+    sd = random_state_dict(cfg, seed=12)
+    ck = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"epoch": 3, "best_loss": 0.0, "optimizer": {},
+                "state_dict": {"module." + k: torch.from_numpy(v) for k, v in sd.items()}}, ck)
+    n = 48
+    batch = synth.make_sites(n, reads=100, seed=57)
+    recs = hdf5io.records_from_sites(batch)
+    rng = np.random.default_rng(1)
+    for i in (5, 30):
+        recs[i]["num_reads"] = 150
+        recs[i]["single_reads"][100:150] = recs[i]["single_reads"][rng.integers(0, 100, 50)]
+    hdf = str(tmp_path / "candidates.hdf")
+    hdf5io.write_candidates(hdf, recs)
+    sample = str(tmp_path / "candidates.vcf")
+    open(sample, "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n")
+    out = str(tmp_path / "model_test.vcf")
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--test_file", hdf, "--modelload", ck, "--sample_vcf", sample,
+           "--save_vcf_records", "--save_vcf_records_file", out, "--reads-seed", "91", "--sites-per-launch", "16",
+           "--precision", precision] + MODEL_FLAGS
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ours = str(tmp_path / "epoch1_model_test.vcf")
+    # B: the oracle's scores through the same writer (dl4vc/utils.py:146-178's format)
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    theirs = start_scored_vcf(sample, str(refdir / "model_test.vcf"))
+    with hdf5io.CandidateFile(hdf) as f:
+        for b0 in range(0, n, 16):
+            b = assemble_batch(f.read(b0, min(n, b0 + 16)), 100, seed=91 + b0)
+            o = dan_forward_oracle(sd, cfg, *b.arrays())
+            append_scored_records(theirs, o["bp"], o["vt_prob"], b.vcfrec)
+    rep = str(tmp_path / "acceptance.json")
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_calls.py"), ours, theirs, "--candidates", hdf, "--json", rep],
+                       capture_output=True, text=True)
+    print(c.stdout)
+    assert c.returncode == 0, c.stdout[-2000:] + c.stderr[-1000:]
+    d = json.load(open(rep))
+    assert d["ok"] and d["records_a"] == n and d["sites_with_more_reads_than_the_reference_keeps"] == 2 and d["sites_deterministic"] == n - 2
+    assert d["genotype_differences"]["elsewhere"]["count"] == 0
+    assert all(v["max_abs_diff"] <= 1e-4 for v in d["scores"].values())
