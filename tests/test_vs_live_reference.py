@@ -167,3 +167,84 @@ def test_random_scored_vcfs_through_format_vcf_equal_reference(ref, tmp_path):
             fv.filter_format_vcf(a)
         got = "".join(vcf.format_vcf_lines(text.splitlines(keepends=True), vcf.FormatOptions(**vcf.PIPELINE_OPTIONS)))
         assert got == open(pout).read(), "trial %d" % trial
+
+
+def test_acceptance_tool_derives_the_genotype_lines_the_reference_program_writes(ref, tmp_path):
+    """tools/compare_calls.py judges the real-data run.  Its genotype lines must be what the reference's
+    OWN tools/format_vcf.py writes from the same scored file: random pairs of scored VCFs (the second = the first with score noise of
+    a few 1e-5, some sites pushed across a threshold) go through the reference program, the two outputs are diffed record by record,
+    and dl4vc_amd.compare must report exactly that set of differing records -- split into knife-edge and elsewhere by ITS attribution,
+    which is then checked against the scores."""
+    import importlib
+    from dl4vc_amd import vcf
+    from dl4vc_amd.compare import compare_scored_vcfs
+    with contextlib.redirect_stdout(io.StringIO()):
+        fv = importlib.import_module("format_vcf")
+    rng = np.random.default_rng(17)
+    header = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tCALLED\n"
+    alleles_pool = [("A", "G"), ("C", "T"), ("AT", "A"), ("A", "AT"), ("ATG", "A"), ("A", "ATGC"), ("G", "C"), ("T", "A")]
+
+    def run_reference(text, tag):
+        pin, pout = str(tmp_path / (tag + ".in.vcf")), str(tmp_path / (tag + ".out.vcf"))
+        open(pin, "w").write(text)
+        a = types.SimpleNamespace(input_file=pin, output_file=pout, snp_threshold=0.1, indel_threshold=0.2,
+                                  long_indel_threshold=0.0, delete_threshold=0.0, snp_zygo_threshold=0.75,
+                                  indel_zygo_threshold=0.8, long_indel_zygo_threshold=0.5, delete_zygo_threshold=0.5,
+                                  multiallele_second_threshold=0.7, multiallele_homozygous_second_threshold=0.9, debug=False)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            fv.filter_format_vcf(a)
+        out = {}
+        for line in open(pout):
+            if not line.startswith("#"):
+                c = line.rstrip("\n").split("\t")
+                out[(c[0], c[1], c[3], c[4])] = c[9].split(":")[0]
+        return out
+
+    total_diff = 0
+    for trial in range(12):
+        recs, pos, used = [], 100, set()
+        for _ in range(int(rng.integers(20, 60))):
+            if rng.random() < 0.7:
+                pos += int(rng.integers(1, 50))
+                used = set()
+            cands = [a for a in alleles_pool if a not in used]
+            if not cands:
+                continue
+            ref_s, alt_s = cands[int(rng.integers(0, len(cands)))]
+            used.add((ref_s, alt_s))
+            p = rng.dirichlet((0.6, 0.6, 0.6))
+            if rng.random() < 0.25:                                  # plant the call score next to the SNP / indel threshold
+                thr = 0.1 if (len(ref_s) == 1 and len(alt_s) == 1) else 0.2
+                nv = 1.0 - thr + rng.uniform(-3e-5, 3e-5)
+                p = np.array([nv, (1 - nv) * 0.7, (1 - nv) * 0.3])
+            recs.append((pos, ref_s, alt_s, p))
+
+        def text_of(scores):
+            return header + "".join("\t".join(("chr2", str(pos), "BP=%.8f;NV=%.8f;HV=%.8f;OV=%.8f" % (1 - s[0], s[0], s[1], s[2]), r, al,
+                                               "50", ".", "DP=30;AF=0.5", "GT:GQ", "1:50")) + "\n" for (pos, r, al, _), s in zip(recs, scores))
+        sa = [p for _, _, _, p in recs]
+        sb = []
+        for p in sa:
+            d = rng.normal(0, 2e-5, 3)
+            q = np.clip(p + d - d.mean(), 0, 1)
+            sb.append(q)
+        ta, tb = text_of(sa), text_of(sb)
+        # (the pipeline sorts the scored file before format_vcf -- call_variants.sh:151, `sort -k1,1 -k2,2n`, ties by the whole line --
+        # and so does the tool; the reference program gets the sorted text, as it does in the pipeline)
+        srt = lambda t: "".join(vcf.sort_scored_vcf_lines(t.splitlines(keepends=True)))      # noqa: E731
+        ga, gb = run_reference(srt(ta), "a%d" % trial), run_reference(srt(tb), "b%d" % trial)
+        want = {k for k in set(ga) | set(gb) if ga.get(k) != gb.get(k)}
+        rep = compare_scored_vcfs(ta.splitlines(keepends=True), tb.splitlines(keepends=True), vcf.FormatOptions(**vcf.PIPELINE_OPTIONS), max_listed=1000)
+        got = set()
+        for kind in ("knife_edge", "elsewhere"):
+            for e in rep["genotype_differences"][kind]["first"]:
+                m = e["site"]
+                chrom_pos, alle = m.split(" ")
+                chrom, pos = chrom_pos.split(":")
+                r, al = alle.split(">")
+                got.add((chrom, pos, r, al))
+        assert got == want, (trial, got ^ want)
+        # every difference between two files 2e-5 apart is a knife edge by the tool's own attribution
+        assert rep["genotype_differences"]["elsewhere"]["count"] == 0 and rep["ok"], rep["genotype_differences"]["elsewhere"]
+        total_diff += len(want)
+    assert total_diff >= 5, "the trials produced too few threshold crossings to test anything: %d" % total_diff
