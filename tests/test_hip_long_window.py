@@ -109,10 +109,39 @@ def test_long_window_structures_all_forms_agree(name):
     the direct form, empty rows computed once per site (persistent workgroups walking (row, unit) pairs) and 2-site chunks --
     the last two bit-identical to the first."""
     kw = dict(LONG_STRUCTURES[name], fc_sizes=(32, 16))
-    cfg = DanConfig(**kw)
-    seed = 900 + sorted(LONG_STRUCTURES).index(name)
+    _all_forms_agree(name, DanConfig(**kw), 900 + sorted(LONG_STRUCTURES).index(name), 5)
+
+
+def _random_long_structure(seed):
+    """tests/test_hip_parity.py::random_structure at 209..304 columns, with the dilations drawn as well (dilation 2 everywhere: the
+    Winograd form, six tiles per lane on the split kernel; anything else: the direct form on the 13-tile image; dilation 3-4 and many
+    layers: bf16x3 units above 192 columns, its seven-tile split form)."""
+    from test_hip_parity import random_structure
+    kw, n = random_structure(seed, (209, 305))
+    rng = np.random.default_rng(7000 + seed)
+    if rng.random() < 0.5:
+        kw["dil_mid"], kw["dil_final"] = int(rng.integers(1, 5)), int(rng.choice([1, 2, 4]))
+    return kw, max(2, n)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 110)))
+def test_long_window_random_structures_all_forms_agree(seed):
+    """Round 6: the split kernels were re-tiled for the window (six Winograd tiles per lane / six column tiles per wave for units of
+    up to 190 / 192 columns); the five named structures above are joined by seeded random ones -- reads, window 209..304, layers,
+    pools, residual start, widths, bottleneck, input planes, dilations -- through the same checks.  A structure whose segment reaches
+    further sideways than a unit has room for is refused by dan_create (and skipped here)."""
+    kw, n = _random_long_structure(seed)
+    try:
+        DanNet(DanConfig(**kw)).close()
+    except RuntimeError as e:
+        assert "sideways" in str(e), e
+        pytest.skip("refused by dan_create: %s" % str(e)[:80])
+    _all_forms_agree("seed %d %s" % (seed, kw), DanConfig(**kw), 4000 + seed, n)
+
+
+def _all_forms_agree(name, cfg, seed, n_sites):
     sd = random_state_dict(cfg, seed=seed)
-    batch = synth.make_sites(5, reads=cfg.reads, length=cfg.length, seed=seed + 50)
+    batch = synth.make_sites(n_sites, reads=cfg.reads, length=cfg.length, seed=seed + 50)
     want = dan_forward_oracle(sd, cfg, *batch.arrays())
     outs = {}
     for tag, c, kwn in (("auto", cfg, {}), ("direct", dataclasses.replace(cfg, conv_algo=1), {}),
