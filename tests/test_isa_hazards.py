@@ -49,6 +49,12 @@ def test_shipped_kernels_have_no_unprotected_mfma_result_read(obj, tmp_path):
     bad = [b for name, items in kernels.items() for b in H.check_kernel(name, items)]
     msg = "\n".join("%s: [%d] %s -> [%d] %s: %d wait states on some path, %d needed" % b for b in bad[:10])
     assert not bad, "%d unprotected MFMA-result accesses in %s:\n%s" % (len(bad), obj, msg)
+    # ... and the classic gfx9 wait-state rules (VALU-written SGPR read by vector memory / taken as a lane select, DPP after a VALU
+    # write of its source or of EXEC, a wide store's data registers overwritten), over every path as well: the recognizer's hole is
+    # not specific to MFMAs
+    classic = [b for name, items in kernels.items() for b in H.check_kernel_classic(name, items)]
+    msg = "\n".join("%s: [%d] %s -> [%d] %s: %d wait states on some path, %d needed (%s)" % b for b in classic[:10])
+    assert not classic, "%d classic wait-state violations in %s:\n%s" % (len(classic), obj, msg)
     print("%s: %d kernels, %d MFMAs, every path protected" % (obj, len(kernels), n_mfma))
 
 
@@ -152,3 +158,37 @@ def test_the_join_of_the_skip_last_branch_carries_its_own_wait_states():
     src = open(os.path.join(CSRC, "dan_kernels_bf16x.hip")).read()
     body = src[src.index("__device__ __forceinline__ void gemm_x("):src.index("__device__ __forceinline__ void load_first(")]
     assert 'asm volatile("s_nop 7");' in body.split("sched_group_barrier(0x020, 4, 0);")[-1]
+
+
+def _classic(body):
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("_Z1kv:\n" + body + "\ts_endpgm\n")
+    try:
+        kernels = H.parse(f.name)
+        return [(b[7], b[5], b[6]) for name, items in kernels.items() for b in H.check_kernel_classic(name, items)]
+    finally:
+        os.remove(f.name)
+
+
+def test_classic_wait_state_rules_fire_where_they_should_and_only_there():
+    """tools/isa_hazard_check.py::check_kernel_classic on hand-written listings: each rule with too few wait states, with exactly
+    enough, and across a branch join (the hole's shape)."""
+    sgpr = "VALU writes an SGPR, a vector-memory instruction reads it"
+    assert _classic("\tv_readfirstlane_b32 s4, v0\n\tglobal_load_dword v1, v2, s[4:5]\n") == [(sgpr, 0, 5)]
+    assert _classic("\tv_readfirstlane_b32 s4, v0\n\ts_nop 4\n\tglobal_load_dword v1, v2, s[4:5]\n") == []
+    assert _classic("\tv_cmp_lt_i32_e64 s[8:9], s0, v182\n\ts_nop 1\n\tglobal_store_dwordx4 v39, v[150:153], s[8:9]\n") == [(sgpr, 2, 5)]
+    assert _classic("\tv_readfirstlane_b32 s4, v0\n\tglobal_load_dword v1, v2, s[6:7]\n") == []                      # another SGPR
+    dpp = "VALU writes a VGPR, a DPP instruction reads it"
+    assert _classic("\tv_mov_b32_e32 v1, v2\n\tv_mov_b32_dpp v3, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n") == [(dpp, 0, 2)]
+    assert _classic("\tv_mov_b32_e32 v1, v2\n\ts_nop 1\n\tv_mov_b32_dpp v3, v1 row_shl:1 row_mask:0xf bank_mask:0xf\n") == []
+    store = "a vector-memory store of more than 64 bits, a VALU instruction overwrites its data registers"
+    assert _classic("\tglobal_store_dwordx4 v0, v[2:5], s[0:1]\n\tv_mov_b32_e32 v3, 0\n") == [(store, 0, 2)]
+    assert _classic("\tglobal_store_dwordx4 v0, v[2:5], s[0:1]\n\ts_nop 1\n\tv_mov_b32_e32 v3, 0\n") == []
+    assert _classic("\tglobal_store_dwordx2 v0, v[2:3], s[0:1]\n\tv_mov_b32_e32 v3, 0\n") == []                      # 64 bits: no hazard
+    lane = "VALU writes an SGPR / VCC, v_readlane / v_writelane takes it as the lane select"
+    assert _classic("\tv_add_co_u32_e32 v6, vcc, 0x4000, v30\n\tv_readlane_b32 s3, v5, vcc_lo\n") == [(lane, 0, 4)]
+    # the hole's shape: the producer in front of a branch over a short block, the consumer first at the join
+    tri = "\tv_readfirstlane_b32 s4, v0\n\ts_cbranch_scc1 .L1\n\tv_mov_b32_e32 v9, 0\n\tv_mov_b32_e32 v8, 0\n\tv_mov_b32_e32 v7, 0\n\tv_mov_b32_e32 v6, 0\n.L1:\n\t%sglobal_load_dword v1, v2, s[4:5]\n"
+    assert _classic(tri % "") == [(sgpr, 1, 5)]                   # the fall-through path has 5, the taken one 1
+    assert _classic(tri % "s_nop 3\n\t") == []

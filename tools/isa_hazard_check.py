@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Static check of a gfx950 assembly listing for ONE software-managed hazard, over every control-flow path:
+"""Static check of a gfx950 assembly listing for the wait states the hardware leaves to software, over every control-flow path:
 
-    an MFMA writes VGPRs  ->  a VALU / LDS / vector-memory instruction reads or overwrites them too few wait states later.
+    an MFMA writes VGPRs  ->  a VALU / LDS / vector-memory instruction reads or overwrites them too few wait states later
+    (check_kernel; the failure this tool came from), and the classic gfx9 rules (check_kernel_classic): a VALU-written SGPR read by
+    vector memory (5) or taken as a v_readlane / v_writelane lane select (4), a DPP instruction behind a VALU write of its source (2) or
+    of EXEC (5), a VALU write of the data registers of a store of more than 64 bits (2).
 
 gfx940 / gfx950 have no hardware interlock for this: the compiler must place `s_nop`s (CDNA3 ISA guide section 4.5; LLVM
 GCNHazardRecognizer::checkMAIVALUHazards).  ROCm 7.2's recognizer walks the predecessors of a block with ONE `Visited` set for all
@@ -33,6 +36,60 @@ def regs(text):
             out.add((m.group(1), int(m.group(4))))
         else:
             out.update((m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+SREG = re.compile(r"\bs(?:\[(\d+):(\d+)\]|(\d+)\b)")
+
+
+def sregs(text):
+    """SGPRs named in ``text`` (s5, s[4:7], vcc = ("vcc", 0/1), exec, m0)."""
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(3) is not None:
+            out.add(("s", int(m.group(3))))
+        else:
+            out.update(("s", r) for r in range(int(m.group(1)), int(m.group(2)) + 1))
+    for name in ("vcc", "exec", "m0"):
+        if re.search(r"\b%s(_lo|_hi)?\b" % name, text):
+            out.add((name, 0))
+    return out
+
+
+def operands(t):
+    op = t.split()[0]
+    rest = t[len(op):]
+    return op, [x.strip() for x in rest.split(",")] if rest.strip() else []
+
+
+def is_valu(op):
+    return op.startswith("v_") and not op.startswith(("v_mfma", "v_smfmac"))
+
+
+def is_vmem(op):
+    return op.startswith(("global_", "buffer_", "flat_", "scratch_"))
+
+
+def valu_sgpr_writes(t):
+    """SGPRs (and vcc / exec) a VALU instruction writes."""
+    op, ops = operands(t)
+    if not is_valu(op):
+        return set()
+    out = set()
+    if op.startswith(("v_readlane", "v_readfirstlane")) and ops:
+        out |= sregs(ops[0])
+    elif op.startswith("v_cmpx"):
+        out.add(("exec", 0))
+        if op.endswith("_e64") and ops:
+            out |= sregs(ops[0])
+    elif op.startswith("v_cmp"):
+        if ops and (ops[0].startswith("s") or ops[0].startswith("vcc")) and (op.endswith("_e64") or len(ops) == 3):
+            out |= sregs(ops[0])
+        else:
+            out.add(("vcc", 0))
+    elif re.match(r"v_(add|sub|subrev|addc|subb|subbrev)_co_", op) or op.startswith(("v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32")):
+        if len(ops) > 1:
+            out |= sregs(ops[1])                    # the carry / flag destination is the second operand
     return out
 
 
@@ -138,6 +195,91 @@ def check_kernel(name, items):
     return bad
 
 
+# ---- the classic gfx9 wait-state rules (CDNA3 ISA guide section 4.5; LLVM checkVMEMHazards / checkRWLaneHazards / checkDPPHazards /
+# checkVALUHazardsHelper), searched over every path like the MFMA rule: the recognizer's hole (one visited-set for all paths) is not
+# specific to MFMAs.  (name, wait states needed)
+RULES = (("VALU writes an SGPR, a vector-memory instruction reads it", 5),
+         ("VALU writes an SGPR / VCC, v_readlane / v_writelane takes it as the lane select", 4),
+         ("VALU writes a VGPR, a DPP instruction reads it", 2),
+         ("VALU writes EXEC, a DPP instruction follows", 5),
+         ("a vector-memory store of more than 64 bits, a VALU instruction overwrites its data registers", 2))
+
+
+def check_kernel_classic(name, items):
+    ins = []
+    label_at = {}
+    for kind, t in items:
+        if kind == "label":
+            label_at[t] = len(ins)
+        else:
+            ins.append(t)
+    n = len(ins)
+    preds = [[] for _ in range(n)]
+    for i, t in enumerate(ins):
+        op = t.split()[0]
+        tgt = None
+        if op.startswith(("s_cbranch", "s_branch")):
+            tgt = label_at.get(re.sub(r"^<|>$", "", t.split()[-1]))
+        if tgt is not None and tgt < n:
+            preds[tgt].append(i)
+        if op != "s_branch" and not op.startswith("s_endpgm") and i + 1 < n:
+            preds[i + 1].append(i)
+    ws = [int(t.split()[1], 0) + 1 if t.split()[0] == "s_nop" else 1 for t in ins]
+    swr = [valu_sgpr_writes(t) for t in ins]
+    bad = []
+
+    def search(i, need, hit):
+        best = {}
+        stack = [(p, 0) for p in preds[i]]
+        while stack:
+            j, acc = stack.pop()
+            if acc >= need or best.get(j, 1 << 30) <= acc:
+                continue
+            best[j] = acc
+            if hit(j):
+                bad_pair.append((j, acc))
+                continue
+            for p in preds[j]:
+                stack.append((p, acc + ws[j]))
+
+    for i, t in enumerate(ins):
+        op, ops = operands(t)
+        dpp = " dpp" in t or "quad_perm" in t or "row_shr" in t or "row_shl" in t or "row_ror" in t or "row_bcast" in t or "row_mirror" in t or "row_half_mirror" in t or "wave_shr" in t or "wave_ror" in t or "row_newbcast" in t
+        checks = []
+        if is_vmem(op):
+            used = sregs(t) - {("exec", 0), ("m0", 0)}
+            if used:
+                checks.append((0, lambda j, used=used: bool(swr[j] & used)))
+        if op.startswith(("v_readlane", "v_writelane")) and len(ops) >= 3:
+            sel = sregs(ops[2])
+            if sel:
+                checks.append((1, lambda j, sel=sel: bool(swr[j] & sel)))
+        if dpp and is_valu(op):
+            src = regs(",".join(ops[1:]))
+            checks.append((2, lambda j, src=src: is_valu(ins[j].split()[0]) and bool(regs(operands(ins[j])[1][0] if operands(ins[j])[1] else "") & src)))
+            checks.append((3, lambda j: ("exec", 0) in swr[j]))
+        if is_valu(op) and ops:
+            dst = regs(ops[0])
+            if dst:
+                def store_hit(j, dst=dst):
+                    o2, p2 = operands(ins[j])
+                    if not (is_vmem(o2) and "store" in o2 and ("x3" in o2 or "x4" in o2)):
+                        return False
+                    data = set()
+                    for x in p2:
+                        r = regs(x)
+                        if len(r) >= 3:
+                            data |= r
+                    return bool(data & dst)
+                checks.append((4, store_hit))
+        for rule, hit in checks:
+            bad_pair = []
+            search(i, RULES[rule][1], hit)
+            for j, acc in bad_pair:
+                bad.append((name, j, ins[j], i, t, acc, RULES[rule][1], RULES[rule][0]))
+    return bad
+
+
 def main(paths):
     total = 0
     for path in paths:
@@ -153,6 +295,14 @@ def main(paths):
                 seen.add(key)
                 total += 1
                 print("%s: %s\n    [%d] %s\n    [%d] %s\n    %d wait state(s) on some path, %d needed" % (path, b[0], b[1], b[2], b[3], b[4], b[5], b[6]))
+            seen = set()
+            for b in check_kernel_classic(name, items):
+                key = (b[1], b[3], b[7])
+                if key in seen:
+                    continue
+                seen.add(key)
+                total += 1
+                print("%s: %s  (%s)\n    [%d] %s\n    [%d] %s\n    %d wait state(s) on some path, %d needed" % (path, b[0], b[7], b[1], b[2], b[3], b[4], b[5], b[6]))
         print("%s: %d kernels, %d MFMAs checked" % (path, len(ks), n_mfma))
     print("violations: %d" % total)
     return 1 if total else 0
